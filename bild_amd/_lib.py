@@ -1,0 +1,209 @@
+"""
+ctypes binding of ``libbild_amd.so`` (C ABI: include/bild_amd.h).
+
+There is no CPU fallback: if the shared library is missing or no GPU is usable, every
+evaluation raises.  (The reference's warn-and-fall-back shim, bild/cython_imports.py:3-7,
+is deliberately *not* mirrored: a silent fallback would void the parity claims.)
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libbild_amd.so')
+
+OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_NOMEM = range(6)
+
+PATH_AUTO, PATH_DENSE, PATH_MODAL = 0, 1, 2
+PATHS = {'auto': PATH_AUTO, 'dense': PATH_DENSE, 'modal': PATH_MODAL}
+MODEL_NO_REDUCE = 1
+
+Q_N, Q_D, Q_S, Q_MODAL_OK, Q_NP, Q_NEFF, Q_HAS_G = range(7)
+X_LAMBDA, X_SIGMA, X_Q, X_WQ, X_R, X_C0Q, X_V = range(7)
+
+
+class BildAmdError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"bild_amd error {code}: {message}")
+        self.code = code
+
+
+class NoDeviceError(BildAmdError):
+    pass
+
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int32)
+_vp = ctypes.c_void_p
+
+_SIGNATURES = {
+    'bild_abi_version': (ctypes.c_int, []),
+    'bild_last_error': (ctypes.c_char_p, []),
+    'bild_device_count': (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    'bild_model_create': (ctypes.c_int, [ctypes.c_int] * 3 + [_dp] * 6 + [ctypes.c_uint, ctypes.POINTER(_vp)]),
+    'bild_model_destroy': (ctypes.c_int, [_vp]),
+    'bild_model_query': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int64)]),
+    'bild_model_export': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, ctypes.c_int64]),
+    'bild_trajset_create': (ctypes.c_int, [_vp, ctypes.c_int, _ip, _dp, _dp, ctypes.POINTER(_vp)]),
+    'bild_trajset_destroy': (ctypes.c_int, [_vp]),
+    'bild_logl_segments': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, _ip, _ip, _ip, ctypes.c_uint, _dp]),
+    'bild_logl_profiles': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int64, _ip, _ip, ctypes.c_uint, _dp]),
+    'bild_logl_segments_device': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, _vp, _vp, _vp,
+                                                 ctypes.c_uint, _vp, _vp]),
+    'bild_flop_count': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, _ip, ctypes.c_uint, _dp, _dp]),
+    'bild_kernel_timing': (ctypes.c_int, [ctypes.c_int]),
+    'bild_kernel_timing_read': (ctypes.c_int, [_dp, ctypes.POINTER(ctypes.c_int64), ctypes.c_char_p, ctypes.c_int]),
+}
+
+_lib = None
+
+
+def lib():
+    """ load libbild_amd.so (raises if it has not been built) """
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              f"or `make -C bild_amd/csrc` (there is no CPU fallback)")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        if handle.bild_abi_version() != 1:
+            raise ImportError("libbild_amd.so ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+def exported_symbols():
+    return list(_SIGNATURES)
+
+
+def check(code):
+    if code != OK:
+        msg = lib().bild_last_error().decode()
+        raise (NoDeviceError if code == ERR_NO_DEVICE else BildAmdError)(code, msg)
+
+
+def device_count():
+    c = ctypes.c_int(0)
+    check(lib().bild_device_count(ctypes.byref(c)))
+    return c.value
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def dptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+def iptr(a):
+    return None if a is None else a.ctypes.data_as(_ip)
+
+
+class ModelHandle:
+    """ owns a ``bild_model*`` """
+
+    def __init__(self, B, G, Sig, M0, C0, w, reduce=True):
+        B, G, Sig, M0, C0, w = (f64(a) for a in (B, G, Sig, M0, C0, w))
+        S, N, d = G.shape
+        if B.shape != (S, N, N) or Sig.shape != (S, N, N) or C0.shape != (S, N, N) \
+                or M0.shape != (S, N, d) or w.shape != (N,):
+            raise AssertionError("inconsistent model array shapes")  # reference: pyx:165-166 asserts
+        self.N, self.d, self.S = N, d, S
+        self._h = _vp()
+        check(lib().bild_model_create(N, d, S, dptr(B), dptr(G), dptr(Sig), dptr(M0), dptr(C0), dptr(w),
+                                      0 if reduce else MODEL_NO_REDUCE, ctypes.byref(self._h)))
+
+    def query(self, what):
+        v = ctypes.c_int64(0)
+        check(lib().bild_model_query(self._h, what, ctypes.byref(v)))
+        return v.value
+
+    def export(self, what, s=0, s2=0):
+        n = self.query(Q_NEFF)
+        shape = {X_LAMBDA: (n,), X_SIGMA: (n,), X_Q: (n, n), X_WQ: (n,), X_R: (n, n), X_C0Q: (n, n),
+                 X_V: (self.N, n)}[what]
+        buf = np.empty(shape, dtype=np.float64)
+        check(lib().bild_model_export(self._h, what, s, s2, dptr(buf), buf.size))
+        return buf
+
+    def __del__(self):
+        if getattr(self, '_h', None) and _lib is not None:
+            _lib.bild_model_destroy(self._h)
+            self._h = None
+
+
+class TrajSetHandle:
+    """ owns a ``bild_trajset*`` (device-resident trajectories) """
+
+    def __init__(self, model, trajs, loc_errs):
+        self.model = model  # keep alive
+        arrs = [f64(t) for t in trajs]
+        for a in arrs:
+            if a.ndim != 2 or a.shape[1] != model.d:
+                raise AssertionError(f"trajectory shape {a.shape} does not match model dimension d={model.d}")
+        self.T = i32([a.shape[0] for a in arrs])
+        x = f64(np.concatenate(arrs, axis=0))
+        err = f64(loc_errs).reshape(len(arrs), model.d)
+        self.n_traj = len(arrs)
+        self._h = _vp()
+        check(lib().bild_trajset_create(model._h, self.n_traj, iptr(self.T), dptr(x), dptr(err), ctypes.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, '_h', None) and _lib is not None:
+            _lib.bild_trajset_destroy(self._h)
+            self._h = None
+
+
+def logl_segments(model, ts, seg_start, seg_state, traj_id=None, path='auto'):
+    seg_start, seg_state = i32(seg_start), i32(seg_state)
+    n, K1 = seg_start.shape
+    assert seg_state.shape == (n, K1)
+    tid = None if traj_id is None else i32(traj_id)
+    out = np.empty(n, dtype=np.float64)
+    check(lib().bild_logl_segments(model._h, ts._h, n, K1, iptr(seg_start), iptr(seg_state), iptr(tid),
+                                   PATHS[path], dptr(out)))
+    return out
+
+
+def logl_profiles(model, ts, states, traj_id=None, path='auto'):
+    states = i32(np.atleast_2d(states))
+    n, ld = states.shape
+    tid = None if traj_id is None else i32(traj_id)
+    out = np.empty(n, dtype=np.float64)
+    check(lib().bild_logl_profiles(model._h, ts._h, n, ld, iptr(states), iptr(tid), PATHS[path], dptr(out)))
+    return out
+
+
+def logl_segments_device(model, ts, n, K1, d_seg_start, d_seg_state, d_traj_id, d_out, stream=0, path='auto'):
+    """ raw device pointers (ints); asynchronous on `stream` """
+    check(lib().bild_logl_segments_device(model._h, ts._h, n, K1, _vp(d_seg_start), _vp(d_seg_state),
+                                          _vp(d_traj_id) if d_traj_id else None, PATHS[path],
+                                          _vp(stream) if stream else None, _vp(d_out)))
+
+
+def flop_count(model, ts, n, traj_id=None, path='auto'):
+    can, exe = ctypes.c_double(0), ctypes.c_double(0)
+    tid = None if traj_id is None else i32(traj_id)
+    check(lib().bild_flop_count(model._h, ts._h, n, iptr(tid), PATHS[path], ctypes.byref(can), ctypes.byref(exe)))
+    return can.value, exe.value
+
+
+def kernel_timing(enable):
+    check(lib().bild_kernel_timing(1 if enable else 0))
+
+
+def kernel_timing_read():
+    ms, cnt = ctypes.c_double(0), ctypes.c_int64(0)
+    name = ctypes.create_string_buffer(128)
+    check(lib().bild_kernel_timing_read(ctypes.byref(ms), ctypes.byref(cnt), name, 128))
+    return ms.value, cnt.value, name.value.decode()

@@ -1,0 +1,897 @@
+// C ABI of bild_amd (include/bild_amd.h): host-side model analysis, device residency,
+// launches.  Compiled with hipcc together with kernels.hip into libbild_amd.so.
+#include <hip/hip_runtime_api.h>
+
+#include <climits>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/bild_amd.h"
+#include "common.h"
+#include "host_linalg.h"
+
+using namespace bild;
+using la::Mat;
+
+// ------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(call)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice ? BILD_ERR_NO_DEVICE \
+                                                                              : BILD_ERR_HIP,      \
+                        "%s failed: %s", #call, hipGetErrorString(e_));                            \
+    } while (0)
+
+bool all_finite(const double *p, size_t n)
+{
+    for (size_t i = 0; i < n; ++i)
+        if (!std::isfinite(p[i])) return false;
+    return true;
+}
+
+struct DeviceBuf {
+    void *ptr = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes)
+    {
+        if (bytes <= cap) return BILD_OK;
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&ptr, want);
+        if (e != hipSuccess) {
+            ptr = nullptr;
+            return fail(BILD_ERR_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        }
+        cap = want;
+        return BILD_OK;
+    }
+    void release()
+    {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+    }
+};
+
+// kernel timing (bench.py roofline leg)
+std::mutex g_time_mu;
+bool g_time_on = false;
+std::vector<std::pair<hipEvent_t, hipEvent_t>> g_time_events;
+std::string g_time_name;
+
+} // namespace
+
+// ------------------------------------------------------------------------------------
+// model
+// ------------------------------------------------------------------------------------
+struct bild_model {
+    int N = 0, d = 0, S = 0;
+    unsigned flags = 0;
+    // inputs as given
+    Mat B, G, Sig, M0, C0, w;
+    // invariant-subspace reduction: V is N x n (columns orthonormal); r* are the projected arrays
+    int n = 0;
+    Mat V;
+    Mat rB, rG, rSig, rM0, rC0, rw;
+    bool has_G = false;
+    // modal analysis (in reduced coordinates)
+    bool modal_ok = false;
+    std::string modal_why;
+    Mat lam, sigd, Q, wq, R, C0q, M0q, Gq; // S*n, S*n, S*n*n, S*n, S*S*n*n, S*n*n, S*n*d, S*n*d
+    // packed for the kernels
+    Geometry geom{0, 0, 0};
+    Mat blob_states[2], blob_tab[2];
+    // device residency
+    mutable std::mutex mu;
+    mutable int device = -1;
+    mutable double *d_states[2] = {nullptr, nullptr};
+    mutable double *d_tab[2] = {nullptr, nullptr};
+    mutable DeviceBuf ws_seg_start, ws_seg_state, ws_traj_id, ws_out, ws_partial;
+};
+
+struct bild_trajset {
+    const bild_model *model = nullptr;
+    int n_traj = 0;
+    int d = 0;
+    std::vector<TrajDesc> descs; // host copy; .x are device pointers
+    int dstar_max = 1;
+    int Tmax = 0;
+    int device = -1;
+    double *d_x = nullptr;
+    TrajDesc *d_descs = nullptr;
+};
+
+namespace {
+
+// Smallest subspace that contains w (and the mean sources M0, G) and is invariant under every
+// B_s, Sig_s, C0_s.  All of these are symmetric, so the orthogonal complement is invariant as
+// well and decouples exactly from the observable w.x: the filter restricted to the subspace
+// gives the same likelihood.  (For the reference's default model -- free chain vs. chain with
+// an end-to-end bond, end-to-end measurement -- this is the reflection-antisymmetric half of
+// the modes, N/2 instead of N.)
+//
+// A Krylov construction is ill-conditioned here (the remainders decay smoothly, there is no
+// gap to threshold on).  Instead: eigen-decompose ONE generic combination Z of all matrices;
+// every common invariant subspace is spanned by eigenvectors of Z (generic Z has simple
+// eigenvalues within each symmetry sector), so select the eigenvectors that overlap w and
+// close the selection under the couplings  e_i^T X e_j  of every matrix X.  Overlaps and
+// couplings are either O(1e-16) or macroscopic, which makes the threshold robust.
+// Returns the basis as ROWS (n x N).
+void invariant_subspace(const bild_model &m, Mat &rows, int &n)
+{
+    const int N = m.N, S = m.S;
+    const double tol = 1e-11;
+    std::vector<const double *> mats;
+    for (int s = 0; s < S; ++s)
+        for (const Mat *src : {&m.B, &m.Sig, &m.C0}) mats.push_back(src->data() + (size_t)s * N * N);
+    Mat Z((size_t)N * N, 0.0);
+    std::vector<double> scale(mats.size());
+    for (size_t a = 0; a < mats.size(); ++a) {
+        double mx = 0.0;
+        for (int i = 0; i < N * N; ++i) mx = std::max(mx, std::fabs(mats[a][i]));
+        scale[a] = std::max(mx, 1e-300);
+        // fixed irrational-ish weights: reproducible, generic
+        const double c = 0.5 + std::fmod(0.7548776662466927 * (double)(a + 1), 1.0);
+        for (int i = 0; i < N * N; ++i) Z[i] += c * mats[a][i] / scale[a];
+    }
+    std::vector<double> ev;
+    Mat E;
+    la::jacobi_eigh(Z, N, ev, E); // columns
+    Mat Et = la::transpose(E, N, N); // rows = eigenvectors
+
+    std::vector<char> sel(N, 0);
+    auto seed = [&](const double *v, int stride) {
+        double nv = 0.0;
+        for (int i = 0; i < N; ++i) nv += v[(size_t)i * stride] * v[(size_t)i * stride];
+        nv = std::sqrt(nv);
+        if (nv == 0.0) return;
+        for (int e = 0; e < N; ++e) {
+            double dot = 0.0;
+            for (int i = 0; i < N; ++i) dot += Et[(size_t)e * N + i] * v[(size_t)i * stride];
+            if (std::fabs(dot) > tol * nv) sel[e] = 1;
+        }
+    };
+    seed(m.w.data(), 1);
+    for (int s = 0; s < S; ++s)
+        for (int k = 0; k < m.d; ++k) {
+            seed(m.M0.data() + (size_t)s * N * m.d + k, m.d);
+            seed(m.G.data() + (size_t)s * N * m.d + k, m.d);
+        }
+    // coupling matrices in the eigenbasis of Z
+    std::vector<Mat> coup(mats.size());
+    for (size_t a = 0; a < mats.size(); ++a) {
+        Mat X(mats[a], mats[a] + (size_t)N * N);
+        coup[a] = la::matmul(la::matmul(Et, X, N, N, N), E, N, N, N);
+    }
+    bool grew = true;
+    while (grew) {
+        grew = false;
+        for (size_t a = 0; a < mats.size(); ++a)
+            for (int i = 0; i < N; ++i) {
+                if (sel[i]) continue;
+                for (int j = 0; j < N; ++j)
+                    if (sel[j] && std::fabs(coup[a][(size_t)i * N + j]) > tol * scale[a]) {
+                        sel[i] = 1;
+                        grew = true;
+                        break;
+                    }
+            }
+    }
+    rows.clear();
+    n = 0;
+    for (int e = 0; e < N; ++e)
+        if (sel[e]) {
+            rows.insert(rows.end(), Et.begin() + (size_t)e * N, Et.begin() + (size_t)(e + 1) * N);
+            ++n;
+        }
+}
+
+int analyse(bild_model &m)
+{
+    const int N = m.N, d = m.d, S = m.S;
+    m.has_G = la::max_abs(m.G) != 0.0;
+
+    // ---- reduction ------------------------------------------------------------------
+    bool symmetric = true;
+    for (int s = 0; s < S && symmetric; ++s)
+        for (const Mat *src : {&m.B, &m.Sig, &m.C0}) {
+            const double *X = src->data() + (size_t)s * N * N;
+            double scale = 0.0, asym = 0.0;
+            for (int i = 0; i < N; ++i)
+                for (int j = 0; j < N; ++j) {
+                    scale = std::max(scale, std::fabs(X[(size_t)i * N + j]));
+                    asym = std::max(asym, std::fabs(X[(size_t)i * N + j] - X[(size_t)j * N + i]));
+                }
+            if (asym > 1e-12 * std::max(scale, 1e-300)) symmetric = false;
+        }
+
+    Mat rows;
+    int n = N;
+    bool reduced = false;
+    if (symmetric && !(m.flags & BILD_MODEL_NO_REDUCE)) {
+        invariant_subspace(m, rows, n);
+        reduced = n < N && n >= 1;
+    }
+    if (!reduced) {
+        n = N;
+        rows.assign((size_t)N * N, 0.0);
+        for (int i = 0; i < N; ++i) rows[(size_t)i * N + i] = 1.0;
+    }
+    m.n = n;
+    m.V = la::transpose(rows, n, N); // N x n
+    const Mat &Vt = rows;            // n x N
+
+    auto project_sym = [&](const Mat &X3) {
+        Mat out((size_t)S * n * n);
+        for (int s = 0; s < S; ++s) {
+            Mat X(X3.begin() + (size_t)s * N * N, X3.begin() + (size_t)(s + 1) * N * N);
+            Mat t = la::matmul(Vt, X, n, N, N);
+            Mat r = la::matmul(t, m.V, n, N, n);
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j) out[((size_t)s * n + i) * n + j] = reduced ? 0.5 * (r[(size_t)i * n + j] + r[(size_t)j * n + i]) : X[(size_t)i * N + j];
+        }
+        return out;
+    };
+    auto project_vecs = [&](const Mat &X3) {
+        Mat out((size_t)S * n * d);
+        for (int s = 0; s < S; ++s) {
+            Mat X(X3.begin() + (size_t)s * N * d, X3.begin() + (size_t)(s + 1) * N * d);
+            Mat r = la::matmul(Vt, X, n, N, d);
+            std::copy(r.begin(), r.end(), out.begin() + (size_t)s * n * d);
+        }
+        return out;
+    };
+    m.rB = project_sym(m.B);
+    m.rSig = project_sym(m.Sig);
+    m.rC0 = project_sym(m.C0);
+    m.rG = project_vecs(m.G);
+    m.rM0 = project_vecs(m.M0);
+    m.rw = la::matmul(Vt, m.w, n, N, 1);
+
+    if (reduced) {
+        // verify invariance: || X V - V (V^T X V) || small for every matrix; otherwise undo
+        double worst = 0.0;
+        for (int s = 0; s < S; ++s) {
+            const Mat *full[3] = {&m.B, &m.Sig, &m.C0};
+            const Mat *red[3] = {&m.rB, &m.rSig, &m.rC0};
+            for (int a = 0; a < 3; ++a) {
+                Mat X(full[a]->begin() + (size_t)s * N * N, full[a]->begin() + (size_t)(s + 1) * N * N);
+                Mat Xr(red[a]->begin() + (size_t)s * n * n, red[a]->begin() + (size_t)(s + 1) * n * n);
+                Mat XV = la::matmul(X, m.V, N, N, n);
+                Mat VXr = la::matmul(m.V, Xr, N, n, n);
+                double dev = 0.0;
+                for (size_t i = 0; i < XV.size(); ++i) dev = std::max(dev, std::fabs(XV[i] - VXr[i]));
+                worst = std::max(worst, dev / std::max(la::max_abs(X), 1e-300));
+            }
+        }
+        if (worst > 1e-9) {
+            // numerically not invariant enough: keep the full chain
+            m.flags |= BILD_MODEL_NO_REDUCE;
+            return analyse(m);
+        }
+    }
+
+    // ---- modal analysis ---------------------------------------------------------------
+    m.modal_ok = symmetric;
+    m.modal_why = symmetric ? "" : "B, Sig or C0 is not symmetric";
+    m.lam.assign((size_t)S * n, 0.0);
+    m.sigd.assign((size_t)S * n, 0.0);
+    m.Q.assign((size_t)S * n * n, 0.0);
+    m.wq.assign((size_t)S * n, 0.0);
+    m.R.assign((size_t)S * S * n * n, 0.0);
+    m.C0q.assign((size_t)S * n * n, 0.0);
+    m.M0q.assign((size_t)S * n * d, 0.0);
+    m.Gq.assign((size_t)S * n * d, 0.0);
+    if (m.modal_ok) {
+        for (int s = 0; s < S; ++s) {
+            Mat Bs(m.rB.begin() + (size_t)s * n * n, m.rB.begin() + (size_t)(s + 1) * n * n);
+            Mat Ss(m.rSig.begin() + (size_t)s * n * n, m.rSig.begin() + (size_t)(s + 1) * n * n);
+            // B and Sig of a Rouse model are functions of the same connectivity matrix and share
+            // an eigenbasis.  Diagonalise a generic combination so that (near-)degenerate
+            // eigenvalues of B alone (fast modes, exp(-ka) ~ 0) are still resolved.
+            const double nb = std::max(la::fro(Bs), 1e-300), ns = std::max(la::fro(Ss), 1e-300);
+            Mat mix((size_t)n * n);
+            for (size_t i = 0; i < mix.size(); ++i) mix[i] = Bs[i] / nb + 0.61803398874989485 * Ss[i] / ns;
+            std::vector<double> ev;
+            Mat Q;
+            la::jacobi_eigh(mix, n, ev, Q);
+            Mat Qt = la::transpose(Q, n, n);
+            Mat Bq = la::matmul(la::matmul(Qt, Bs, n, n, n), Q, n, n, n);
+            Mat Sq = la::matmul(la::matmul(Qt, Ss, n, n, n), Q, n, n, n);
+            double offB = 0.0, offS = 0.0;
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j)
+                    if (i != j) {
+                        offB = std::max(offB, std::fabs(Bq[(size_t)i * n + j]));
+                        offS = std::max(offS, std::fabs(Sq[(size_t)i * n + j]));
+                    }
+            if (offB > 1e-13 * std::max(la::max_abs(Bs), 1e-300) || offS > 1e-13 * std::max(la::max_abs(Ss), 1e-300)) {
+                m.modal_ok = false;
+                char buf[160];
+                snprintf(buf, sizeof buf, "state %d: B and Sig do not share an eigenbasis (off-diagonal %.2e / %.2e)", s,
+                         offB, offS);
+                m.modal_why = buf;
+                break;
+            }
+            for (int i = 0; i < n; ++i) {
+                m.lam[(size_t)s * n + i] = Bq[(size_t)i * n + i];
+                m.sigd[(size_t)s * n + i] = Sq[(size_t)i * n + i];
+            }
+            std::copy(Q.begin(), Q.end(), m.Q.begin() + (size_t)s * n * n);
+            Mat ws(m.rw);
+            Mat wqs = la::matmul(Qt, ws, n, n, 1);
+            std::copy(wqs.begin(), wqs.end(), m.wq.begin() + (size_t)s * n);
+            Mat C0s(m.rC0.begin() + (size_t)s * n * n, m.rC0.begin() + (size_t)(s + 1) * n * n);
+            Mat C0qs = la::matmul(la::matmul(Qt, C0s, n, n, n), Q, n, n, n);
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j)
+                    m.C0q[((size_t)s * n + i) * n + j] = 0.5 * (C0qs[(size_t)i * n + j] + C0qs[(size_t)j * n + i]);
+            Mat M0s(m.rM0.begin() + (size_t)s * n * d, m.rM0.begin() + (size_t)(s + 1) * n * d);
+            Mat Gs(m.rG.begin() + (size_t)s * n * d, m.rG.begin() + (size_t)(s + 1) * n * d);
+            Mat M0qs = la::matmul(Qt, M0s, n, n, d), Gqs = la::matmul(Qt, Gs, n, n, d);
+            std::copy(M0qs.begin(), M0qs.end(), m.M0q.begin() + (size_t)s * n * d);
+            std::copy(Gqs.begin(), Gqs.end(), m.Gq.begin() + (size_t)s * n * d);
+        }
+    }
+    if (m.modal_ok) {
+        for (int s2 = 0; s2 < S; ++s2)
+            for (int s = 0; s < S; ++s) {
+                Mat Q2(m.Q.begin() + (size_t)s2 * n * n, m.Q.begin() + (size_t)(s2 + 1) * n * n);
+                Mat Q1(m.Q.begin() + (size_t)s * n * n, m.Q.begin() + (size_t)(s + 1) * n * n);
+                Mat Rm = la::matmul(la::transpose(Q2, n, n), Q1, n, n, n);
+                std::copy(Rm.begin(), Rm.end(), m.R.begin() + ((size_t)s2 * S + s) * n * n);
+            }
+    }
+
+    // ---- pack --------------------------------------------------------------------------
+    if (!geometry_for(n, &m.geom))
+        return fail(BILD_ERR_UNSUPPORTED, "chain of %d effective modes exceeds the compiled kernels (max %d)", n, kMaxNP);
+    const int NP = m.geom.NP;
+    const int SB = StateBlock::size(NP);
+    const int MS = table_stride(NP);
+    for (int mode = 0; mode < 2; ++mode) {
+        Mat &sb = m.blob_states[mode];
+        Mat &tb = m.blob_tab[mode];
+        sb.assign((size_t)S * SB, 0.0);
+        const int ntab = mode == kDense ? 2 * S : S * S;
+        tb.assign((size_t)ntab * MS, 0.0);
+        if (mode == kModal && !m.modal_ok) continue;
+        for (int s = 0; s < S; ++s) {
+            double *b = sb.data() + (size_t)s * SB;
+            const double *C0src = mode == kDense ? m.rC0.data() + (size_t)s * n * n : m.C0q.data() + (size_t)s * n * n;
+            const double *M0src = mode == kDense ? m.rM0.data() + (size_t)s * n * d : m.M0q.data() + (size_t)s * n * d;
+            const double *Gsrc = mode == kDense ? m.rG.data() + (size_t)s * n * d : m.Gq.data() + (size_t)s * n * d;
+            for (int i = 0; i < n; ++i) {
+                b[StateBlock::wq(NP) + i] = mode == kDense ? m.rw[i] : m.wq[(size_t)s * n + i];
+                if (mode == kModal) {
+                    b[StateBlock::lam(NP) + i] = m.lam[(size_t)s * n + i];
+                    b[StateBlock::sig(NP) + i] = m.sigd[(size_t)s * n + i];
+                }
+                for (int k = 0; k < d; ++k) {
+                    b[StateBlock::G(NP) + k * NP + i] = Gsrc[(size_t)i * d + k];
+                    b[StateBlock::M0(NP) + k * NP + i] = M0src[(size_t)i * d + k];
+                }
+                for (int j = 0; j < n; ++j) b[StateBlock::C0(NP) + i * NP + j] = C0src[(size_t)i * n + j];
+            }
+        }
+        auto put = [&](int slot, const double *X) {
+            double *t = tb.data() + (size_t)slot * MS;
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j) t[i * NP + j] = X[(size_t)i * n + j];
+        };
+        if (mode == kDense) {
+            for (int s = 0; s < S; ++s) {
+                put(s, m.rB.data() + (size_t)s * n * n);
+                put(S + s, m.rSig.data() + (size_t)s * n * n);
+            }
+        } else {
+            for (int s2 = 0; s2 < S; ++s2)
+                for (int s = 0; s < S; ++s) put(s2 * S + s, m.R.data() + ((size_t)s2 * S + s) * n * n);
+        }
+    }
+    return BILD_OK;
+}
+
+size_t lds_bytes(const bild_model &m, int mode)
+{
+    // dense: propagator tables + per-group product images; modal: product images only (the
+    // basis-change matrices are read through L2, they are touched only at state switches)
+    const size_t groups = (size_t)kWaves * (64 / m.geom.G);
+    const size_t image = (size_t)m.geom.CPL * m.geom.G * m.geom.NP;
+    return ((mode == kDense ? m.blob_tab[mode].size() : 0) + groups * image) * sizeof(double);
+}
+
+int ensure_device(const bild_model &m)
+{
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(m.mu);
+    if (m.device == dev) return BILD_OK;
+    if (m.device != -1)
+        return fail(BILD_ERR_INVALID, "model is resident on device %d but device %d is current (one process per GPU)", m.device, dev);
+    for (int mode = 0; mode < 2; ++mode) {
+        HIP_TRY(hipMalloc((void **)&m.d_states[mode], m.blob_states[mode].size() * sizeof(double)));
+        HIP_TRY(hipMemcpy(m.d_states[mode], m.blob_states[mode].data(), m.blob_states[mode].size() * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void **)&m.d_tab[mode], m.blob_tab[mode].size() * sizeof(double)));
+        HIP_TRY(hipMemcpy(m.d_tab[mode], m.blob_tab[mode].data(), m.blob_tab[mode].size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    m.device = dev;
+    return BILD_OK;
+}
+
+int pick_mode(const bild_model &m, unsigned flags, int *mode)
+{
+    switch (flags & 0xFu) {
+    case BILD_PATH_AUTO: *mode = m.modal_ok ? kModal : kDense; return BILD_OK;
+    case BILD_PATH_DENSE: *mode = kDense; return BILD_OK;
+    case BILD_PATH_MODAL:
+        if (!m.modal_ok) return fail(BILD_ERR_UNSUPPORTED, "modal path unavailable: %s", m.modal_why.c_str());
+        *mode = kModal;
+        return BILD_OK;
+    default: return fail(BILD_ERR_INVALID, "unknown path selector %u", flags & 0xFu);
+    }
+}
+
+int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1, const int32_t *d_seg_start,
+                 const int32_t *d_seg_state, const int32_t *d_traj_id, unsigned flags, hipStream_t st, double *d_out)
+{
+    int mode;
+    int rc = pick_mode(m, flags, &mode);
+    if (rc) return rc;
+    const size_t lds = lds_bytes(m, mode);
+    if (lds > 160 * 1024)
+        return fail(BILD_ERR_UNSUPPORTED, "model tables need %zu bytes of LDS (> 160 KiB): too many states for chain length %d", lds, m.n);
+
+    KParams p{};
+    p.states = m.d_states[mode];
+    p.tab = m.d_tab[mode];
+    p.tab_doubles = (int32_t)m.blob_tab[mode].size();
+    p.S = m.S;
+    p.d = m.d;
+    p.has_G = m.has_G ? 1 : 0;
+    p.trajs = ts.d_descs;
+    p.dstar_max = ts.dstar_max;
+    p.ntasks = n * ts.dstar_max;
+    p.K1 = K1;
+    p.seg_start = d_seg_start;
+    p.seg_state = d_seg_state;
+    p.traj_id = d_traj_id;
+    double *target = d_out;
+    if (ts.dstar_max > 1) {
+        std::lock_guard<std::mutex> lk(m.mu);
+        rc = m.ws_partial.reserve((size_t)p.ntasks * sizeof(double));
+        if (rc) return rc;
+        target = (double *)m.ws_partial.ptr;
+    }
+    p.out = target;
+
+    const int gpw = 64 / m.geom.G;
+    const int64_t tasks_per_block = (int64_t)kWaves * gpw;
+    int64_t blocks = (p.ntasks + tasks_per_block - 1) / tasks_per_block;
+    const int grid = (int)std::min<int64_t>(std::max<int64_t>(blocks, 1), 256 * 16);
+
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool timing;
+    {
+        std::lock_guard<std::mutex> lk(g_time_mu);
+        timing = g_time_on;
+    }
+    if (timing) {
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, st));
+    }
+    int lrc = launch_logl(m.geom, mode, p, grid, lds, (void *)st);
+    if (lrc != 0) return fail(BILD_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
+    if (timing) {
+        HIP_TRY(hipEventRecord(e1, st));
+        std::lock_guard<std::mutex> lk(g_time_mu);
+        g_time_events.emplace_back(e0, e1);
+        g_time_name = kernel_name(m.geom, mode);
+    }
+    if (ts.dstar_max > 1) {
+        lrc = launch_reduce_partials(target, d_out, n, ts.dstar_max, (void *)st);
+        if (lrc != 0) return fail(BILD_ERR_HIP, "reduce launch failed: %s", hipGetErrorString((hipError_t)lrc));
+    }
+    return BILD_OK;
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------
+// exported
+// ------------------------------------------------------------------------------------
+extern "C" {
+
+int bild_abi_version(void) { return BILD_AMD_ABI_VERSION; }
+
+const char *bild_last_error(void) { return g_err.c_str(); }
+
+int bild_device_count(int *count)
+{
+    if (!count) return fail(BILD_ERR_INVALID, "count is NULL");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    *count = (e == hipSuccess) ? c : 0;
+    return BILD_OK;
+}
+
+int bild_model_create(int N, int d, int S, const double *B, const double *G, const double *Sig, const double *M0,
+                      const double *C0, const double *w, unsigned flags, bild_model **out)
+{
+    if (!out) return fail(BILD_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!B || !G || !Sig || !M0 || !C0 || !w) return fail(BILD_ERR_INVALID, "NULL model array");
+    if (N < 1 || S < 1) return fail(BILD_ERR_INVALID, "need N >= 1 and S >= 1 (got N=%d, S=%d)", N, S);
+    if (d < 1 || d > kDMax) return fail(BILD_ERR_UNSUPPORTED, "spatial dimension d=%d outside 1..%d", d, kDMax);
+    if (S > 255) return fail(BILD_ERR_UNSUPPORTED, "S=%d states exceed 255", S);
+    const size_t nn = (size_t)S * N * N, nd = (size_t)S * N * d;
+    if (!all_finite(B, nn) || !all_finite(Sig, nn) || !all_finite(C0, nn) || !all_finite(G, nd) || !all_finite(M0, nd) ||
+        !all_finite(w, (size_t)N))
+        return fail(BILD_ERR_INVALID, "model arrays contain NaN or Inf");
+    bild_model *m = new (std::nothrow) bild_model;
+    if (!m) return fail(BILD_ERR_NOMEM, "out of memory");
+    m->N = N;
+    m->d = d;
+    m->S = S;
+    m->flags = flags;
+    m->B.assign(B, B + nn);
+    m->Sig.assign(Sig, Sig + nn);
+    m->C0.assign(C0, C0 + nn);
+    m->G.assign(G, G + nd);
+    m->M0.assign(M0, M0 + nd);
+    m->w.assign(w, w + N);
+    int rc = analyse(*m);
+    if (rc) {
+        delete m;
+        return rc;
+    }
+    *out = m;
+    return BILD_OK;
+}
+
+int bild_model_destroy(bild_model *m)
+{
+    if (!m) return BILD_OK;
+    for (int mode = 0; mode < 2; ++mode) {
+        if (m->d_states[mode]) (void)hipFree(m->d_states[mode]);
+        if (m->d_tab[mode]) (void)hipFree(m->d_tab[mode]);
+    }
+    m->ws_seg_start.release();
+    m->ws_seg_state.release();
+    m->ws_traj_id.release();
+    m->ws_out.release();
+    m->ws_partial.release();
+    delete m;
+    return BILD_OK;
+}
+
+int bild_model_query(const bild_model *m, int what, int64_t *value)
+{
+    if (!m || !value) return fail(BILD_ERR_INVALID, "NULL argument");
+    switch (what) {
+    case BILD_Q_N: *value = m->N; break;
+    case BILD_Q_D: *value = m->d; break;
+    case BILD_Q_S: *value = m->S; break;
+    case BILD_Q_MODAL_OK: *value = m->modal_ok; break;
+    case BILD_Q_NP: *value = m->geom.NP; break;
+    case BILD_Q_NEFF: *value = m->n; break;
+    case BILD_Q_HAS_G: *value = m->has_G; break;
+    default: return fail(BILD_ERR_INVALID, "unknown query %d", what);
+    }
+    return BILD_OK;
+}
+
+int bild_model_export(const bild_model *m, int what, int s, int s2, double *buf, int64_t buf_len)
+{
+    if (!m || !buf) return fail(BILD_ERR_INVALID, "NULL argument");
+    const int n = m->n, S = m->S;
+    if (s < 0 || s >= S || s2 < 0 || s2 >= S) return fail(BILD_ERR_INVALID, "state index out of range");
+    const double *src = nullptr;
+    int64_t len = 0;
+    switch (what) {
+    case BILD_X_LAMBDA: src = m->lam.data() + (size_t)s * n; len = n; break;
+    case BILD_X_SIGMA: src = m->sigd.data() + (size_t)s * n; len = n; break;
+    case BILD_X_Q: src = m->Q.data() + (size_t)s * n * n; len = (int64_t)n * n; break;
+    case BILD_X_WQ: src = m->wq.data() + (size_t)s * n; len = n; break;
+    case BILD_X_R: src = m->R.data() + ((size_t)s2 * S + s) * n * n; len = (int64_t)n * n; break;
+    case BILD_X_C0Q: src = m->C0q.data() + (size_t)s * n * n; len = (int64_t)n * n; break;
+    case BILD_X_V: src = m->V.data(); len = (int64_t)m->N * n; break;
+    default: return fail(BILD_ERR_INVALID, "unknown export %d", what);
+    }
+    if (what != BILD_X_V && !m->modal_ok) return fail(BILD_ERR_UNSUPPORTED, "modal analysis unavailable: %s", m->modal_why.c_str());
+    if (buf_len < len) return fail(BILD_ERR_INVALID, "buffer too small: need %lld doubles", (long long)len);
+    std::memcpy(buf, src, (size_t)len * sizeof(double));
+    return BILD_OK;
+}
+
+int bild_trajset_create(const bild_model *m, int n_traj, const int32_t *T, const double *x, const double *loc_err,
+                        bild_trajset **out)
+{
+    if (!out) return fail(BILD_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!m || !T || !x || !loc_err) return fail(BILD_ERR_INVALID, "NULL argument");
+    if (n_traj < 1) return fail(BILD_ERR_INVALID, "need at least one trajectory");
+    const int d = m->d;
+    int64_t total = 0;
+    for (int j = 0; j < n_traj; ++j) {
+        if (T[j] < 1) return fail(BILD_ERR_INVALID, "trajectory %d has length %d < 1", j, T[j]);
+        total += T[j];
+    }
+    for (int64_t i = 0; i < (int64_t)n_traj * d; ++i)
+        if (!(loc_err[i] >= 0.0) || !std::isfinite(loc_err[i]))
+            return fail(BILD_ERR_INVALID, "localization error must be finite and >= 0");
+
+    int rc = ensure_device(*m);
+    if (rc) return rc;
+
+    bild_trajset *ts = new (std::nothrow) bild_trajset;
+    if (!ts) return fail(BILD_ERR_NOMEM, "out of memory");
+    ts->model = m;
+    ts->n_traj = n_traj;
+    ts->d = d;
+    ts->device = m->device;
+    ts->descs.resize(n_traj);
+
+    // device copy of the data: a frame with any NaN coordinate is missing (pyx:178) -> all NaN
+    std::vector<double> xd((size_t)total * d);
+    const double qnan = std::nan("");
+    int64_t off = 0;
+    auto cleanup = [&](int code) {
+        if (ts->d_x) (void)hipFree(ts->d_x);
+        if (ts->d_descs) (void)hipFree(ts->d_descs);
+        delete ts;
+        return code;
+    };
+    hipError_t he = hipMalloc((void **)&ts->d_x, std::max<size_t>(xd.size(), 1) * sizeof(double));
+    if (he != hipSuccess) return cleanup(fail(BILD_ERR_NOMEM, "hipMalloc failed: %s", hipGetErrorString(he)));
+    for (int j = 0; j < n_traj; ++j) {
+        TrajDesc &td = ts->descs[j];
+        std::memset(&td, 0, sizeof td);
+        td.T = T[j];
+        td.x = ts->d_x + off * d;
+        int nvalid = 0;
+        for (int t = 0; t < T[j]; ++t) {
+            bool valid = true;
+            for (int k = 0; k < d; ++k) valid &= !std::isnan(x[(off + t) * d + k]);
+            for (int k = 0; k < d; ++k) xd[(off + t) * d + k] = valid ? x[(off + t) * d + k] : qnan;
+            nvalid += valid;
+        }
+        td.nvalid = nvalid;
+        // np.unique(err, return_inverse=True): sorted unique values (pyx:145)
+        double uniq[kDMax];
+        int nu = 0;
+        for (int k = 0; k < d; ++k) {
+            const double e = loc_err[(size_t)j * d + k];
+            bool seen = false;
+            for (int u = 0; u < nu; ++u) seen |= uniq[u] == e;
+            if (!seen) uniq[nu++] = e;
+        }
+        std::sort(uniq, uniq + nu);
+        td.dstar = nu;
+        for (int u = 0; u < nu; ++u) {
+            td.s2[u] = uniq[u] * uniq[u];
+            td.ndims[u] = 0;
+        }
+        for (int k = 0; k < d; ++k) {
+            const double e = loc_err[(size_t)j * d + k];
+            for (int u = 0; u < nu; ++u)
+                if (uniq[u] == e) td.dims[u][td.ndims[u]++] = k;
+        }
+        ts->dstar_max = std::max(ts->dstar_max, nu);
+        ts->Tmax = std::max(ts->Tmax, (int)T[j]);
+        off += T[j];
+    }
+    he = hipMemcpy(ts->d_x, xd.data(), xd.size() * sizeof(double), hipMemcpyHostToDevice);
+    if (he != hipSuccess) return cleanup(fail(BILD_ERR_HIP, "hipMemcpy failed: %s", hipGetErrorString(he)));
+    he = hipMalloc((void **)&ts->d_descs, (size_t)n_traj * sizeof(TrajDesc));
+    if (he != hipSuccess) return cleanup(fail(BILD_ERR_NOMEM, "hipMalloc failed: %s", hipGetErrorString(he)));
+    he = hipMemcpy(ts->d_descs, ts->descs.data(), (size_t)n_traj * sizeof(TrajDesc), hipMemcpyHostToDevice);
+    if (he != hipSuccess) return cleanup(fail(BILD_ERR_HIP, "hipMemcpy failed: %s", hipGetErrorString(he)));
+    *out = ts;
+    return BILD_OK;
+}
+
+int bild_trajset_destroy(bild_trajset *ts)
+{
+    if (!ts) return BILD_OK;
+    if (ts->d_x) (void)hipFree(ts->d_x);
+    if (ts->d_descs) (void)hipFree(ts->d_descs);
+    delete ts;
+    return BILD_OK;
+}
+
+static int check_eval_args(const bild_model *m, const bild_trajset *ts, int64_t n, int K1)
+{
+    if (!m || !ts) return fail(BILD_ERR_INVALID, "NULL handle");
+    if (ts->model != m) return fail(BILD_ERR_INVALID, "trajectory set belongs to a different model");
+    if (n < 0) return fail(BILD_ERR_INVALID, "negative batch size");
+    if (K1 < 1) return fail(BILD_ERR_INVALID, "need at least one segment per sample");
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev != ts->device) return fail(BILD_ERR_INVALID, "trajectory set lives on device %d, current device is %d", ts->device, dev);
+    return BILD_OK;
+}
+
+int bild_logl_segments_device(const bild_model *m, const bild_trajset *ts, int64_t n, int K1, const int32_t *d_seg_start,
+                              const int32_t *d_seg_state, const int32_t *d_traj_id, unsigned flags, void *hip_stream,
+                              double *d_out)
+{
+    int rc = check_eval_args(m, ts, n, K1);
+    if (rc) return rc;
+    if (n == 0) return BILD_OK;
+    if (!d_seg_start || !d_seg_state || !d_out) return fail(BILD_ERR_INVALID, "NULL device buffer");
+    return launch_batch(*m, *ts, n, K1, d_seg_start, d_seg_state, d_traj_id, flags, (hipStream_t)hip_stream, d_out);
+}
+
+int bild_logl_segments(const bild_model *m, const bild_trajset *ts, int64_t n, int K1, const int32_t *seg_start,
+                       const int32_t *seg_state, const int32_t *traj_id, unsigned flags, double *out)
+{
+    int rc = check_eval_args(m, ts, n, K1);
+    if (rc) return rc;
+    if (n == 0) return BILD_OK;
+    if (!seg_start || !seg_state || !out) return fail(BILD_ERR_INVALID, "NULL buffer");
+    // validate on the host: these indices drive device addressing
+    for (int64_t r = 0; r < n; ++r) {
+        const int tj = traj_id ? traj_id[r] : 0;
+        if (tj < 0 || tj >= ts->n_traj) return fail(BILD_ERR_INVALID, "traj_id[%lld]=%d out of range", (long long)r, tj);
+        if (seg_start[r * K1] != 0) return fail(BILD_ERR_INVALID, "seg_start[%lld][0] must be 0", (long long)r);
+        for (int i = 0; i < K1; ++i) {
+            const int sv = seg_state[r * K1 + i];
+            if (sv < 0 || sv >= m->S) return fail(BILD_ERR_INVALID, "state %d out of range at sample %lld", sv, (long long)r);
+            if (i > 0 && seg_start[r * K1 + i] < seg_start[r * K1 + i - 1])
+                return fail(BILD_ERR_INVALID, "segment starts of sample %lld are decreasing", (long long)r);
+        }
+    }
+    const size_t segbytes = (size_t)n * K1 * sizeof(int32_t);
+    int32_t *d_start, *d_state, *d_tid = nullptr;
+    double *d_out;
+    {
+        std::lock_guard<std::mutex> lk(m->mu);
+        if ((rc = m->ws_seg_start.reserve(segbytes))) return rc;
+        if ((rc = m->ws_seg_state.reserve(segbytes))) return rc;
+        if ((rc = m->ws_out.reserve((size_t)n * sizeof(double)))) return rc;
+        if (traj_id && (rc = m->ws_traj_id.reserve((size_t)n * sizeof(int32_t)))) return rc;
+        d_start = (int32_t *)m->ws_seg_start.ptr;
+        d_state = (int32_t *)m->ws_seg_state.ptr;
+        d_out = (double *)m->ws_out.ptr;
+        if (traj_id) d_tid = (int32_t *)m->ws_traj_id.ptr;
+    }
+    HIP_TRY(hipMemcpy(d_start, seg_start, segbytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_state, seg_state, segbytes, hipMemcpyHostToDevice));
+    if (traj_id) HIP_TRY(hipMemcpy(d_tid, traj_id, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
+    rc = launch_batch(*m, *ts, n, K1, d_start, d_state, d_tid, flags, nullptr, d_out);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    HIP_TRY(hipMemcpy(out, d_out, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    return BILD_OK;
+}
+
+int bild_logl_profiles(const bild_model *m, const bild_trajset *ts, int64_t n, int64_t ld, const int32_t *states,
+                       const int32_t *traj_id, unsigned flags, double *out)
+{
+    if (!m || !ts) return fail(BILD_ERR_INVALID, "NULL handle");
+    if (n < 0) return fail(BILD_ERR_INVALID, "negative batch size");
+    if (n == 0) return BILD_OK;
+    if (!states || !out) return fail(BILD_ERR_INVALID, "NULL buffer");
+    // run-length encode
+    std::vector<int> nseg((size_t)n);
+    int K1 = 1;
+    for (int64_t r = 0; r < n; ++r) {
+        const int tj = traj_id ? traj_id[r] : 0;
+        if (tj < 0 || tj >= ts->n_traj) return fail(BILD_ERR_INVALID, "traj_id[%lld]=%d out of range", (long long)r, tj);
+        const int T = ts->descs[tj].T;
+        if (ld < T) return fail(BILD_ERR_INVALID, "profile row stride %lld shorter than trajectory length %d", (long long)ld, T);
+        int c = 1;
+        for (int t = 1; t < T; ++t) c += states[r * ld + t] != states[r * ld + t - 1];
+        nseg[r] = c;
+        K1 = std::max(K1, c);
+    }
+    std::vector<int32_t> seg_start((size_t)n * K1), seg_state((size_t)n * K1);
+    for (int64_t r = 0; r < n; ++r) {
+        const int tj = traj_id ? traj_id[r] : 0;
+        const int T = ts->descs[tj].T;
+        int c = 0;
+        seg_start[r * K1] = 0;
+        seg_state[r * K1] = states[r * ld];
+        for (int t = 1; t < T; ++t)
+            if (states[r * ld + t] != states[r * ld + t - 1]) {
+                ++c;
+                seg_start[r * K1 + c] = t;
+                seg_state[r * K1 + c] = states[r * ld + t];
+            }
+        for (int i = c + 1; i < K1; ++i) {
+            seg_start[r * K1 + i] = INT_MAX;
+            seg_state[r * K1 + i] = seg_state[r * K1 + c];
+        }
+    }
+    return bild_logl_segments(m, ts, n, K1, seg_start.data(), seg_state.data(), traj_id, flags, out);
+}
+
+int bild_flop_count(const bild_model *m, const bild_trajset *ts, int64_t n, const int32_t *traj_id, unsigned flags,
+                    double *canonical, double *executed)
+{
+    if (!m || !ts || !canonical || !executed) return fail(BILD_ERR_INVALID, "NULL argument");
+    int mode;
+    int rc = pick_mode(*m, flags, &mode);
+    if (rc) return rc;
+    const double N = m->N, d = m->d, nr = m->n;
+    double can = 0.0, exe = 0.0;
+    for (int64_t r = 0; r < n; ++r) {
+        const int tj = traj_id ? traj_id[r] : 0;
+        if (tj < 0 || tj >= ts->n_traj) return fail(BILD_ERR_INVALID, "traj_id out of range");
+        const TrajDesc &td = ts->descs[tj];
+        const double T = td.T, Tv = td.nvalid, ds = td.dstar;
+        can += (T - 1) * (4 * N * N * N * ds + 2 * N * N * d) + Tv * ((4 * N * N + 3 * N) * ds + 4 * N * d);
+        if (mode == kDense)
+            exe += (T - 1) * (4 * nr * nr * nr * ds + 2 * nr * nr * d) + Tv * ((4 * nr * nr + 3 * nr) * ds + 4 * nr * d);
+        else // elementwise predict (2 mul / entry) + update; basis changes at state switches not counted
+            exe += (T - 1) * (2 * nr * nr * ds + nr * ds + 2 * nr * d) + Tv * ((4 * nr * nr + 3 * nr) * ds + 4 * nr * d);
+    }
+    *canonical = can;
+    *executed = exe;
+    return BILD_OK;
+}
+
+int bild_kernel_timing(int enable)
+{
+    std::lock_guard<std::mutex> lk(g_time_mu);
+    g_time_on = enable != 0;
+    return BILD_OK;
+}
+
+int bild_kernel_timing_read(double *total_ms, int64_t *launches, char *name, int name_len)
+{
+    if (!total_ms || !launches) return fail(BILD_ERR_INVALID, "NULL argument");
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    std::string nm;
+    {
+        std::lock_guard<std::mutex> lk(g_time_mu);
+        ev.swap(g_time_events);
+        nm = g_time_name;
+    }
+    double tot = 0.0;
+    for (auto &pr : ev) {
+        HIP_TRY(hipEventSynchronize(pr.second));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
+        tot += ms;
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    *total_ms = tot;
+    *launches = (int64_t)ev.size();
+    if (name && name_len > 0) {
+        std::snprintf(name, (size_t)name_len, "%s", nm.c_str());
+    }
+    return BILD_OK;
+}
+
+} // extern "C"

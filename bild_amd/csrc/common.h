@@ -1,0 +1,71 @@
+// Shared host/device definitions for the Rouse Kalman-filter log-likelihood kernels.
+#pragma once
+#include <stdint.h>
+
+namespace bild {
+
+constexpr int kDMax = 3;      // spatial dimensions supported (reference default d = 3, models.py:222)
+constexpr int kThreads = 256; // threads per workgroup = 4 wavefronts of 64
+constexpr int kWaves = kThreads / 64;
+constexpr int kMaxNP = 32;    // largest padded chain length with a compiled kernel
+
+enum Mode : int { kDense = 0, kModal = 1 };
+
+// Per-state block of the packed model ("state blob"), in doubles.  Vectors are padded to NP
+// rows with zeros, matrices to NP x NP.
+//   dense: lam/sig unused, wq = w,      G/M0/C0 as given
+//   modal: lam = eig(B), wq = Q^T w, sig = diag(Q^T Sig Q), G = Q^T G, M0 = Q^T M0, C0 = Q^T C0 Q
+struct StateBlock {
+    static constexpr int lam(int)     { return 0; }
+    static constexpr int wq(int NP)   { return NP; }
+    static constexpr int sig(int NP)  { return 2 * NP; }
+    static constexpr int G(int NP)    { return 3 * NP; }               // [kDMax][NP]
+    static constexpr int M0(int NP)   { return (3 + kDMax) * NP; }     // [kDMax][NP]
+    static constexpr int C0(int NP)   { return (3 + 2 * kDMax) * NP; } // [NP][NP]
+    static constexpr int size(int NP) { return (3 + 2 * kDMax) * NP + NP * NP; }
+};
+
+// Matrices that live in LDS for the whole kernel ("table"): stride padded by 2 doubles so the
+// same element of different matrices falls into different LDS banks.
+//   dense: B[s] at slot s, Sig[s] at slot S + s                     (2 S matrices)
+//   modal: R[s2][s] = Q[s2]^T Q[s] at slot s2 * S + s               (S*S matrices)
+constexpr int table_stride(int NP) { return NP * NP + 2; }
+
+struct TrajDesc {
+    const double *x; // device, T x d; every coordinate of a missing frame is NaN
+    int32_t T;
+    int32_t dstar;           // number of distinct localization errors (pyx:145)
+    double s2[kDMax];        // their squares, ascending
+    int32_t ndims[kDMax];    // dims that use covariance chain e
+    int32_t dims[kDMax][kDMax];
+    int32_t nvalid;          // frames with data
+    int32_t pad_;
+};
+
+struct KParams {
+    const double *states; // S state blocks
+    const double *tab;    // table matrices
+    int32_t tab_doubles;
+    int32_t S, d, has_G;
+    const TrajDesc *trajs;
+    int64_t ntasks; // n samples * dstar_max
+    int32_t dstar_max;
+    int32_t K1;
+    const int32_t *seg_start;
+    const int32_t *seg_state;
+    const int32_t *traj_id; // may be null
+    double *out;            // ntasks partial results
+};
+
+// launch geometry for a padded chain length
+struct Geometry {
+    int NP, CPL, G;
+};
+
+// host-callable launchers implemented in kernels.hip
+int launch_logl(const Geometry &g, int mode, const KParams &p, int grid, size_t lds_bytes, void *stream);
+int launch_reduce_partials(const double *partial, double *out, int64_t n, int dstar_max, void *stream);
+bool geometry_for(int n_rows, Geometry *g);
+const char *kernel_name(const Geometry &g, int mode);
+
+} // namespace bild

@@ -1,0 +1,453 @@
+// Rouse Kalman-filter log-likelihood kernels for gfx950 (MI355X, CDNA4).
+//
+// What is computed (reference bild/src/MSRouse_logL.pyx:186-256, MSRouse_logL_py.py:96-121):
+// for every task = (sample, covariance chain e) a T-step Kalman filter over the N-monomer
+// chain, observed through y = w.x with localization noise s2[e]; the task's result is the
+// sum of the per-frame Gaussian log-densities of the dimensions that use chain e.
+//
+// Mapping to the machine
+// ----------------------
+// * One task runs on a *group* of G lanes of a wavefront (G = 8 for N = 20), 64/G groups
+//   per wave, 4 waves per workgroup.  Recursions are independent, so there is no
+//   inter-workgroup traffic and no grid-level synchronisation.
+// * The filter state is the augmented matrix  A = [ C | M ]  (NP x (NP + d)): covariance
+//   and the d mean vectors.  A is distributed BY COLUMN: lane gl of the group owns columns
+//   gl*CPL .. gl*CPL+CPL-1 in registers (CPL*NP doubles).  With C symmetric,
+//       Cw_j = sum_i w_i C_ij                       is a lane-local dot product,
+//       yhat_dim = sum_i w_i M_i,dim                is the same dot product on an M column,
+//       C_:j -= Cw (Cw_j / S),  M_:dim += Cw (nu/S) are the same lane-local rank-1 update,
+//   so covariance and mean columns are processed by identical code and the only
+//   cross-lane step per frame is an all-gather of the NP numbers Cw through LDS.
+// * kModal: the recursion is carried in the eigenbasis Q_s of the current state's
+//   (symmetric) propagator B_s, where the predict  C <- B C B + Sig  is elementwise,
+//   C'_ij <- lam_i lam_j C'_ij + sig_i delta_ij.  A state switch s -> s2 applies the
+//   orthogonal basis change R = Q_s2^T Q_s:  A <- R A (all columns), C <- C R^T.
+// * kDense: the canonical recursion, C <- B C B + Sig every frame (pyx:220-241), done as
+//   two lane-local mat-vecs per column with an in-group transpose through LDS between
+//   them.  Same code path as the modal basis change.
+// * Propagator / basis-change matrices are staged once per workgroup into LDS and read
+//   as group-wide broadcasts (ds_read_b128); one LDS operand feeds CPL FMAs.
+// * fp64 throughout (v_fma_f64).  No MFMA: on gfx950 the f64 matrix pipe has the same
+//   peak as the f64 vector pipe and N = 20 does not tile 16x16x4.
+// * sum_t log S_t is accumulated as a running product with exponent extraction
+//   (frexp) and one log per task, instead of one log per frame.
+#include <hip/hip_runtime.h>
+#include <limits.h>
+#include <math.h>
+
+#include "common.h"
+
+namespace bild {
+namespace {
+
+constexpr double kLog2Pi = 1.8378770664093453;
+constexpr double kLn2 = 0.69314718055994531;
+
+// Order LDS traffic between lanes of ONE wavefront: DS instructions of a wave execute in
+// issue order, so only the compiler has to be kept from reordering.
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int NP, int CPL>
+struct Cols {
+    double v[CPL][NP];
+};
+
+// Tg[c][i] = sum_k X[i][k] * in[q][k]  for the own columns c = cidx[q]: the product X * A is
+// streamed column-major into the group's LDS image Tg (NC columns of NP doubles), two rows at
+// a time, so no second register image of A is needed.  X is row-major (LDS for the dense
+// propagators, global/L2 for the modal basis changes); one X operand feeds CPL FMAs.
+template <int NP, int CPL, typename XPtr>
+__device__ __forceinline__ void matvec_to_lds(XPtr X, const Cols<NP, CPL> &in, double *__restrict__ Tg,
+                                              const int (&cidx)[CPL])
+{
+#pragma unroll 1
+    for (int i = 0; i < NP; i += 2) {
+        double a0[CPL], a1[CPL];
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) a0[q] = a1[q] = 0.0;
+#pragma unroll
+        for (int k = 0; k < NP; k += 2) {
+            const double2 x0 = *reinterpret_cast<const double2 *>(X + i * NP + k);
+            const double2 x1 = *reinterpret_cast<const double2 *>(X + (i + 1) * NP + k);
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+                a0[q] = fma(x0.x, in.v[q][k], a0[q]);
+                a1[q] = fma(x1.x, in.v[q][k], a1[q]);
+                a0[q] = fma(x0.y, in.v[q][k + 1], a0[q]);
+                a1[q] = fma(x1.y, in.v[q][k + 1], a1[q]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < CPL; ++q)
+            *reinterpret_cast<double2 *>(Tg + cidx[q] * NP + i) = make_double2(a0[q], a1[q]);
+    }
+}
+
+template <int NP, int CPL, int G, int MODE>
+__global__ void __launch_bounds__(kThreads) logl_kernel(const KParams p)
+{
+    constexpr int GPW = 64 / G;          // groups (= tasks in flight) per wavefront
+    constexpr int MS = table_stride(NP); // LDS matrix stride
+    constexpr int SB = StateBlock::size(NP);
+    static_assert(NP % 2 == 0, "rows are read in pairs");
+    static_assert(CPL * G >= NP + kDMax, "not enough columns for [C | M]");
+    static_assert(64 % G == 0, "groups must tile the wavefront");
+
+    extern __shared__ __align__(16) double smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = tid >> 6;
+    const int grp = lane / G;
+    const int gl = lane - grp * G;
+
+    if (MODE == kDense) { // propagators are needed every frame: keep them in LDS
+        for (int i = tid; i < p.tab_doubles; i += kThreads) smem[i] = p.tab[i];
+        __syncthreads();
+    }
+    // per-group scratch: image of X*A, NC columns of NP doubles; its first NP doubles double as
+    // the all-gather buffer of the update
+    constexpr int NC = CPL * G;
+    const int lds_tab = (MODE == kDense) ? p.tab_doubles : 0;
+    double *const scratch = smem + lds_tab + (size_t)(wv * GPW + grp) * (NC * NP);
+
+    int cidx[CPL];
+    bool isC[CPL];
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+        cidx[q] = gl * CPL + q;
+        isC[q] = cidx[q] < NP;
+    }
+
+    const int S = p.S;
+    const int d = p.d;
+    const int K1 = p.K1;
+    const int64_t gstride = (int64_t)gridDim.x * (kWaves * GPW);
+
+    for (int64_t task = ((int64_t)blockIdx.x * kWaves + wv) * GPW + grp; task < p.ntasks; task += gstride) {
+        const int64_t r = task / p.dstar_max;
+        const int e = (int)(task - r * p.dstar_max);
+        const int tj = p.traj_id ? p.traj_id[r] : 0;
+        const TrajDesc *__restrict__ td = p.trajs + tj;
+        if (e >= td->dstar) {
+            if (gl == 0) p.out[task] = 0.0;
+            continue;
+        }
+        const int T = td->T;
+        const double s2 = td->s2[e];
+        const int nd = td->ndims[e];
+        const double *__restrict__ xg = td->x;
+
+        bool isM[CPL];
+        int xoff[CPL];
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+            const int mi = cidx[q] - NP;
+            isM[q] = (mi >= 0) && (mi < nd);
+            xoff[q] = isM[q] ? td->dims[e][mi] : 0;
+        }
+
+        const int32_t *__restrict__ sst = p.seg_start + r * K1;
+        const int32_t *__restrict__ ssv = p.seg_state + r * K1;
+        int seg = 0;
+        int s = ssv[0];
+        int next_start = (K1 > 1) ? sst[1] : INT_MAX;
+
+        // ---- per-state registers -------------------------------------------------
+        double wq[NP];   // measurement vector in the current basis
+        double lam[NP];  // modal: eigenvalues of B_s
+        double mu[CPL];  // modal: column factor (lam_c for covariance columns, 1 for mean columns)
+        double sgc[CPL]; // modal: process-noise variance of the own diagonal element
+        auto load_state = [&](int st) {
+            const double *__restrict__ sb = p.states + (size_t)st * SB;
+#pragma unroll
+            for (int i = 0; i < NP; ++i) wq[i] = sb[StateBlock::wq(NP) + i];
+            if (MODE == kModal) {
+#pragma unroll
+                for (int i = 0; i < NP; ++i) lam[i] = sb[StateBlock::lam(NP) + i];
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) {
+                    mu[q] = isC[q] ? sb[StateBlock::lam(NP) + cidx[q]] : 1.0;
+                    sgc[q] = isC[q] ? sb[StateBlock::sig(NP) + cidx[q]] : 0.0;
+                }
+            }
+        };
+        load_state(s);
+
+        // ---- initial condition: steady state of state profile[0] (pyx:160-163) ----
+        Cols<NP, CPL> col;
+        {
+            const double *__restrict__ sb = p.states + (size_t)s * SB;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+                const double *src = isC[q] ? sb + StateBlock::C0(NP) + cidx[q] * NP
+                                           : sb + StateBlock::M0(NP) + xoff[q] * NP;
+                const double live = (isC[q] || isM[q]) ? 1.0 : 0.0;
+#pragma unroll
+                for (int i = 0; i < NP; ++i) col.v[q][i] = live * src[i];
+            }
+        }
+
+        double acc = 0.0; // sum over own mean columns of nu^2 / S
+        double P = 1.0;   // running product of S (mantissa), exponent in E
+        int E = 0;
+        int nvalid = 0;
+
+        // ---- Kalman update (pyx:19-90) ---------------------------------------------
+        auto update = [&](const double (&xv)[CPL]) {
+            double dotv[CPL];
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+                double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+                for (int i = 0; i < NP; i += 2) {
+                    a0 = fma(wq[i], col.v[q][i], a0);
+                    a1 = fma(wq[i + 1], col.v[q][i + 1], a1);
+                }
+                dotv[q] = a0 + a1;
+            }
+#pragma unroll
+            for (int q = 0; q < CPL; ++q)
+                if (isC[q]) scratch[cidx[q]] = dotv[q];
+            wave_lds_fence();
+            double cw[NP];
+#pragma unroll
+            for (int i = 0; i < NP; i += 2) {
+                const double2 t2 = *reinterpret_cast<const double2 *>(scratch + i);
+                cw[i] = t2.x;
+                cw[i + 1] = t2.y;
+            }
+            wave_lds_fence();
+            double sa = s2, sb2 = 0.0;
+#pragma unroll
+            for (int i = 0; i < NP; i += 2) {
+                sa = fma(wq[i], cw[i], sa);
+                sb2 = fma(wq[i + 1], cw[i + 1], sb2);
+            }
+            const double Sv = sa + sb2;
+            const double Sinv = 1.0 / Sv;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+                const double nu = xv[q] - dotv[q];
+                const double coef = isC[q] ? dotv[q] * Sinv : (isM[q] ? -nu * Sinv : 0.0);
+                if (isM[q]) acc = fma(nu * nu, Sinv, acc);
+#pragma unroll
+                for (int i = 0; i < NP; ++i) col.v[q][i] = fma(-coef, cw[i], col.v[q][i]);
+            }
+            int ex;
+            P = frexp(P * Sv, &ex);
+            E += ex;
+            ++nvalid;
+        };
+
+        auto load_x = [&](int t, double (&xv)[CPL]) -> double {
+            const double *__restrict__ row = xg + (size_t)t * d;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) xv[q] = row[xoff[q]];
+            return row[0];
+        };
+
+        // A <- X A for all columns, then C <- C X^T for the covariance part: two lane-local
+        // multiplies, each streamed through the group's LDS image; the covariance columns are
+        // read back TRANSPOSED after the first one (row c of X*C is column c of (X*C)^T, and
+        // X (X C)^T = (X C X^T)^T = X C X^T).  Used for the dense predict (X = B_s) and the
+        // modal basis change (X = R).  `after_left` runs on the mean columns between the
+        // two multiplies (adds G in the dense predict).
+        auto sandwich = [&](auto X, auto &&after_left) {
+            matvec_to_lds<NP, CPL>(X, col, scratch, cidx);
+            wave_lds_fence();
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+                const int c = cidx[q] < NP ? cidx[q] : cidx[q] * NP; // covariance: walk row c; mean: own column
+                const int st = cidx[q] < NP ? NP : 1;
+#pragma unroll
+                for (int i = 0; i < NP; ++i) col.v[q][i] = scratch[c + i * st];
+            }
+            wave_lds_fence();
+            after_left();
+            matvec_to_lds<NP, CPL>(X, col, scratch, cidx);
+            wave_lds_fence();
+#pragma unroll
+            for (int q = 0; q < CPL; ++q)
+                if (isC[q]) {
+#pragma unroll
+                    for (int i = 0; i < NP; i += 2) {
+                        const double2 t2 = *reinterpret_cast<const double2 *>(scratch + cidx[q] * NP + i);
+                        col.v[q][i] = t2.x;
+                        col.v[q][i + 1] = t2.y;
+                    }
+                }
+            wave_lds_fence();
+        };
+
+        // ---- frame 0: update on the steady state, no predict (pyx:186-190) ----------
+        {
+            double xv[CPL];
+            const double probe = load_x(0, xv);
+            if (!isnan(probe)) update(xv);
+        }
+
+        for (int t = 1; t < T; ++t) {
+            double xv[CPL];
+            const double probe = load_x(t, xv);
+
+            if (t >= next_start) {
+                do {
+                    ++seg;
+                    next_start = (seg + 1 < K1) ? sst[seg + 1] : INT_MAX;
+                } while (t >= next_start);
+                const int sn = ssv[seg];
+                if (sn != s) {
+                    if (MODE == kModal) {
+                        sandwich(p.tab + (size_t)(sn * S + s) * MS, [] {});
+                    }
+                    s = sn;
+                    load_state(s);
+                }
+            }
+
+            // ---- predict (pyx:206-241) ---------------------------------------------
+            if (MODE == kModal) {
+#pragma unroll
+                for (int q = 0; q < CPL; ++q)
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) col.v[q][i] *= lam[i] * mu[q];
+#pragma unroll
+                for (int i = 0; i < NP; ++i)
+                    if (gl == i / CPL) col.v[i % CPL][i] += sgc[i % CPL];
+                if (p.has_G) {
+                    const double *__restrict__ gb = p.states + (size_t)s * SB + StateBlock::G(NP);
+#pragma unroll
+                    for (int q = 0; q < CPL; ++q)
+                        if (isM[q]) {
+#pragma unroll
+                            for (int i = 0; i < NP; ++i) col.v[q][i] += gb[xoff[q] * NP + i];
+                        }
+                }
+            } else {
+                const double *__restrict__ sb = p.states + (size_t)s * SB;
+                const int has_G = p.has_G;
+                sandwich(const_cast<const double *>(smem) + (size_t)s * MS, [&] {
+                    if (has_G) {
+#pragma unroll
+                        for (int q = 0; q < CPL; ++q)
+                            if (isM[q]) {
+#pragma unroll
+                                for (int i = 0; i < NP; ++i) col.v[q][i] += sb[StateBlock::G(NP) + xoff[q] * NP + i];
+                            }
+                    }
+                });
+                // + Sig[:, c] (symmetric: row c of the LDS copy)
+                const double *__restrict__ sg = smem + (size_t)(S + s) * MS;
+#pragma unroll
+                for (int q = 0; q < CPL; ++q)
+                    if (isC[q]) {
+#pragma unroll
+                        for (int i = 0; i < NP; i += 2) {
+                            const double2 t2 = *reinterpret_cast<const double2 *>(sg + cidx[q] * NP + i);
+                            col.v[q][i] += t2.x;
+                            col.v[q][i + 1] += t2.y;
+                        }
+                    }
+            }
+
+            if (!isnan(probe)) update(xv);
+        }
+
+        // ---- sum of the per-frame log-densities (pyx:88, 251-256) ---------------------
+        scratch[gl] = acc;
+        wave_lds_fence();
+        if (gl == 0) {
+            double tot = 0.0;
+#pragma unroll
+            for (int g2 = 0; g2 < G; ++g2) tot += scratch[g2];
+            const double logS = log(P) + (double)E * kLn2;
+            tot += (double)nd * (logS + (double)nvalid * kLog2Pi);
+            p.out[task] = -0.5 * tot;
+        }
+        wave_lds_fence();
+    }
+}
+
+__global__ void reduce_partials_kernel(const double *__restrict__ partial, double *__restrict__ out, int64_t n,
+                                       int dstar_max)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    double tot = 0.0;
+    for (int e = 0; e < dstar_max; ++e) tot += partial[r * dstar_max + e];
+    out[r] = tot;
+}
+
+template <int NP, int CPL, int G>
+int launch_geom(int mode, const KParams &p, int grid, size_t lds, hipStream_t st)
+{
+    hipError_t err;
+    if (mode == kModal) {
+        auto k = logl_kernel<NP, CPL, G, kModal>;
+        err = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err != hipSuccess) return (int)err;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(kThreads), lds, st, p);
+    } else {
+        auto k = logl_kernel<NP, CPL, G, kDense>;
+        err = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err != hipSuccess) return (int)err;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(kThreads), lds, st, p);
+    }
+    return (int)hipGetLastError();
+}
+
+// (rows, columns-per-lane, lanes-per-group); CPL * G >= NP + 3
+constexpr Geometry kGeoms[] = {
+    {4, 1, 8}, {8, 3, 4}, {12, 2, 8}, {16, 3, 8}, {20, 3, 8}, {24, 4, 8}, {28, 4, 8}, {32, 3, 16},
+};
+
+} // namespace
+
+bool geometry_for(int n_rows, Geometry *g)
+{
+    for (const Geometry &c : kGeoms)
+        if (c.NP >= n_rows) {
+            *g = c;
+            return true;
+        }
+    return false;
+}
+
+const char *kernel_name(const Geometry &, int mode) { return mode == kModal ? "logl_kernel<modal>" : "logl_kernel<dense>"; }
+
+int launch_logl(const Geometry &g, int mode, const KParams &p, int grid, size_t lds, void *stream)
+{
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    switch (g.NP) {
+#ifndef BILD_ONLY_NP20
+    case 4: return launch_geom<4, 1, 8>(mode, p, grid, lds, st);
+    case 8: return launch_geom<8, 3, 4>(mode, p, grid, lds, st);
+    case 12: return launch_geom<12, 2, 8>(mode, p, grid, lds, st);
+    case 16: return launch_geom<16, 3, 8>(mode, p, grid, lds, st);
+#endif
+    case 20: return launch_geom<20, 3, 8>(mode, p, grid, lds, st);
+#ifndef BILD_ONLY_NP20
+    case 24: return launch_geom<24, 4, 8>(mode, p, grid, lds, st);
+    case 28: return launch_geom<28, 4, 8>(mode, p, grid, lds, st);
+    case 32: return launch_geom<32, 3, 16>(mode, p, grid, lds, st);
+#endif
+    default: return -1;
+    }
+}
+
+int launch_reduce_partials(const double *partial, double *out, int64_t n, int dstar_max, void *stream)
+{
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int bs = 256;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, st, partial, out, n,
+                       dstar_max);
+    return (int)hipGetLastError();
+}
+
+} // namespace bild

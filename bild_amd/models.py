@@ -1,0 +1,255 @@
+"""
+Inference models: the interface (`MultiStateModel`) and the GPU-backed multi-state Rouse
+model (`MultiStateRouse`).
+
+Counterpart of reference bild/models.py:24-370 for the one hot path this package
+accelerates.  `MultiStateRouse` keeps the reference's constructor, attributes
+(``models``, ``measurement``, ``localization_error``, ``transitions``, ``nStates``, ``d``)
+and ``logL(profile, traj) -> float`` contract, so it can be handed to
+``bild.amis.FixedkSampler`` / ``bild.core.sample`` / ``bild.postproc`` unchanged; in
+addition it offers batched entry points that evaluate a whole AMIS step in one launch.
+
+The likelihood itself runs on the GPU through the C ABI in include/bild_amd.h; there is no
+CPU implementation in this package.
+"""
+import abc
+from collections import OrderedDict
+
+import numpy as np
+
+from . import _lib
+from . import rouse
+from .profiles import Loopingprofile, segments_from_st, segments_from_states
+from .trajectory import Trajectory, as_array
+
+
+class MultiStateModel(metaclass=abc.ABCMeta):
+    """
+    Interface used by the samplers (reference bild/models.py:24-160).
+
+    Attributes
+    ----------
+    transitions : (n, n) bool -- ``transitions[i, j]``: is the switch i -> j allowed
+    """
+
+    def init_transitions(self, n):
+        self.transitions = ~np.eye(n, dtype=bool)
+
+    @property
+    def nStates(self):
+        return self.transitions.shape[0]
+
+    @property
+    def d(self):
+        raise NotImplementedError  # pragma: no cover
+
+    def initial_loopingprofile(self, traj):
+        return Loopingprofile(np.random.choice(self.nStates, size=len(traj)))
+
+    @abc.abstractmethod
+    def logL(self, loopingprofile, traj):
+        raise NotImplementedError  # pragma: no cover
+
+
+class MultiStateRouse(MultiStateModel):
+    """
+    Multi-state Rouse model with a Kalman-filter likelihood evaluated on the GPU.
+
+    Parameters are those of reference bild/models.py:222-228:
+
+    N : int -- number of monomers
+    D, k : float -- Rouse parameters
+    d : int -- spatial dimension (1..3)
+    looppositions : tuple -- per state ``None`` (no extra bond), ``(i, j[, rel_strength])`` or a
+        list of such
+    measurement : "end2end" or (N,) array
+    localization_error : float, (d,) array or None (then ``traj.localization_error`` is used)
+
+    Extra keyword:
+    path : 'auto' | 'modal' | 'dense' -- kernel path (see include/bild_amd.h)
+    """
+
+    def __init__(self, N, D, k, d=3,
+                 looppositions=(None, (0, -1)),
+                 measurement="end2end",
+                 localization_error=None,
+                 path='auto',
+                 ):
+        self._d = d
+
+        if str(measurement) == "end2end":
+            measurement = np.zeros(N)
+            measurement[0] = -1
+            measurement[-1] = 1
+        measurement = np.asarray(measurement, dtype=np.float64)
+        assert len(measurement) == N
+        self.measurement = measurement
+
+        if localization_error is not None and np.isscalar(localization_error):
+            localization_error = localization_error * np.ones(d)
+        self.localization_error = localization_error
+
+        self.models = []
+        for loop in looppositions:
+            if loop is not None and np.isscalar(loop[0]):
+                loop = [loop]
+            self.models.append(rouse.Model(N, D, k, d, add_bonds=loop))
+
+        self.init_transitions(len(self.models))
+
+        self.path = path
+        self._handle = None
+        self._trajsets = OrderedDict()  # small LRU of device-resident trajectory sets
+
+    # ------------------------------------------------------------------ interface
+    @property
+    def d(self):
+        return self._d
+
+    def _get_noise(self, traj):
+        # precedence model > trajectory > error: reference bild/models.py:255-263
+        if self.localization_error is not None:
+            return np.asarray(self.localization_error)
+        elif getattr(traj, 'localization_error', None) is not None:
+            return np.asarray(traj.localization_error)
+        else:
+            raise ValueError("No localization error specified (use MultiStateModel.localization_error "
+                             "or Trajectory.localization_error)")
+
+    # ------------------------------------------------------------------ device state
+    @classmethod
+    def from_arrays(cls, B, G, Sig, M0, C0, measurement, localization_error=None, path='auto'):
+        """
+        Build directly from per-state arrays (e.g. taken from an installed ``rouse``:
+        ``m._dynamics['B'|'G'|'Sig']`` and ``m.steady_state()``), bypassing this package's
+        own Rouse matrix builder.
+        """
+        self = cls.__new__(cls)
+        G = np.asarray(G, dtype=np.float64)
+        S, N, d = G.shape
+        self._d = d
+        self.measurement = np.asarray(measurement, dtype=np.float64)
+        if localization_error is not None and np.isscalar(localization_error):
+            localization_error = localization_error * np.ones(d)
+        self.localization_error = localization_error
+        self.models = None
+        self._arrays = dict(B=B, G=G, Sig=Sig, M0=M0, C0=C0)
+        self.init_transitions(S)
+        self.path = path
+        self._handle = None
+        self._trajsets = OrderedDict()
+        return self
+
+    def arrays(self):
+        """ stacked (B, G, Sig, M0, C0) over states, as the kernel consumes them (pyx:152-163) """
+        if self.models is None:
+            return self._arrays
+        return rouse.stack_dynamics(self.models)
+
+    def handle(self):
+        if self._handle is None:
+            a = self.arrays()
+            self._handle = _lib.ModelHandle(a['B'], a['G'], a['Sig'], a['M0'], a['C0'], self.measurement)
+        return self._handle
+
+    def invalidate(self):
+        """ call after changing ``models`` / ``measurement`` in place """
+        self._handle = None
+        self._trajsets.clear()
+
+    def trajset(self, trajs):
+        """
+        Device-resident set of trajectories (uploaded once, reused across AMIS steps).
+
+        trajs : a trajectory or a list of trajectories
+        """
+        if not isinstance(trajs, (list, tuple)):
+            trajs = [trajs]
+        noises = [np.asarray(self._get_noise(t), dtype=np.float64) for t in trajs]
+        arrs = [as_array(t) for t in trajs]
+        key = tuple((id(t), a.shape, a.tobytes() if a.size <= 4096 else hash(a.tobytes()), n.tobytes())
+                    for t, a, n in zip(trajs, arrs, noises))
+        ts = self._trajsets.get(key)
+        if ts is None:
+            ts = _lib.TrajSetHandle(self.handle(), arrs, np.stack(noises))
+            self._trajsets[key] = ts
+            while len(self._trajsets) > 8:
+                self._trajsets.popitem(last=False)
+        else:
+            self._trajsets.move_to_end(key)
+        return ts
+
+    # ------------------------------------------------------------------ likelihood
+    def logL(self, profile, traj):
+        """
+        log p(traj | profile, model), reference bild/models.py:265-278 -> MSRouse_logL.
+
+        Returns
+        -------
+        float
+        """
+        states = np.asarray(profile[:])
+        assert len(states) == len(traj)
+        return float(_lib.logl_profiles(self.handle(), self.trajset(traj), states[None, :], path=self.path)[0])
+
+    def logL_batch(self, profiles, traj):
+        """ many expanded profiles on one trajectory: (n, T) int array or list of Loopingprofile -> (n,) """
+        if not isinstance(profiles, np.ndarray):
+            profiles = np.stack([np.asarray(p[:]) for p in profiles])
+        seg_start, seg_state = segments_from_states(profiles)
+        return _lib.logl_segments(self.handle(), self.trajset(traj), seg_start, seg_state, path=self.path)
+
+    def logL_st_batch(self, ss, thetas, traj):
+        """
+        One AMIS batch in (s, theta) parametrisation: what reference
+        ``FixedkSampler.logL(ss, thetas)`` (bild/amis.py:717-739) computes with a Python loop.
+        """
+        seg_start, seg_state = segments_from_st(ss, thetas, len(traj))
+        return _lib.logl_segments(self.handle(), self.trajset(traj), seg_start, seg_state, path=self.path)
+
+    def logL_st(self, s, theta, traj):
+        """ the per-sample hook the reference sampler prefers when present (bild/amis.py:734-736) """
+        return float(self.logL_st_batch(np.asarray(s)[None, :], np.asarray(theta)[None, :], traj)[0])
+
+    def logL_segments(self, seg_start, seg_state, trajs, traj_id=None):
+        """ general batch: run-length encoded profiles over a set of trajectories """
+        return _lib.logl_segments(self.handle(), self.trajset(trajs), seg_start, seg_state, traj_id, path=self.path)
+
+    # ------------------------------------------------------------------ generative model
+    def trajectory_from_loopingprofile(self, profile, localization_error=None, missing_frames=None, rng=None):
+        """
+        Sample a trajectory from the model (reference bild/models.py:295-350): steady-state
+        conformation of ``profile[0]``, propagate with ``profile[t]``, measure, blank the
+        missing frames, then add localization noise.
+        """
+        rng = np.random.default_rng() if rng is None else rng
+        if localization_error is None:
+            if self.localization_error is None:
+                raise ValueError("Need to specify either localization_error or model.localization_error")
+            localization_error = self.localization_error
+        if np.isscalar(localization_error):
+            localization_error = self.d * [localization_error]
+        localization_error = np.asarray(localization_error, dtype=np.float64)
+        if localization_error.shape != (self.d,):
+            raise ValueError("Did not understand localization_error")
+
+        T = len(profile)
+        if missing_frames is None or (np.isscalar(missing_frames) and missing_frames == 0):
+            missing = np.array([], dtype=int)
+        elif np.isscalar(missing_frames):
+            if 0 < missing_frames < 1:
+                missing = np.nonzero(rng.random(T) < missing_frames)[0]
+            else:
+                missing = rng.choice(T, size=int(missing_frames), replace=False).astype(int)
+        else:
+            missing = np.asarray(missing_frames, dtype=int)
+
+        data = np.full((T, self.d), np.nan)
+        conf = self.models[profile[0]].conf_ss(rng)
+        data[0] = self.measurement @ conf
+        for i in range(1, T):
+            conf = self.models[profile[i]].evolve(conf, rng)
+            data[i] = self.measurement @ conf
+        data[missing, :] = np.nan
+        data += localization_error[None, :] * rng.standard_normal(data.shape)
+        return Trajectory(data, localization_error=localization_error, loopingprofile=profile)

@@ -1,0 +1,178 @@
+/*
+ * bild_amd -- C ABI of the MI355X (gfx950) Rouse Kalman-filter log-likelihood.
+ *
+ * This is the drop-in boundary for the one hot path of BILD
+ * (OpenTrajectoryAnalysis/bild): everything the reference does per candidate looping
+ * profile inside
+ *
+ *     bild/src/MSRouse_logL.pyx:95-256   MSRouse_logL(model, profile, traj)        (native)
+ *     bild/src/MSRouse_logL_py.py:54-121 MSRouse_logL(model, profile, traj)        (fallback)
+ *
+ * batched over the samples of one AMIS step, i.e. the loop of
+ *
+ *     bild/amis.py:717-739               FixedkSampler.logL(ss, thetas) -> (N,) float64
+ *
+ * Plain C: opaque handles, raw pointers and sizes.  No torch / numpy / HIP types appear
+ * in any signature (a HIP stream is passed as void*).  All matrices are row-major
+ * float64.  Every function returns a bild_status; bild_last_error() gives the message of
+ * the calling thread's most recent failure.  There is NO CPU fallback: evaluation
+ * functions fail with BILD_ERR_NO_DEVICE when no gfx950 device is usable.
+ *
+ * The reference-side binding a maintainer would add is shown in INTEGRATION.md.
+ */
+#ifndef BILD_AMD_H
+#define BILD_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BILD_AMD_ABI_VERSION 1
+
+typedef enum bild_status {
+    BILD_OK              = 0,
+    BILD_ERR_INVALID     = 1, /* bad argument: NULL, shape, range, non-finite model       */
+    BILD_ERR_HIP         = 2, /* HIP runtime call failed                                  */
+    BILD_ERR_NO_DEVICE   = 3, /* no usable GPU                                            */
+    BILD_ERR_UNSUPPORTED = 4, /* model outside the compiled kernel envelope (N, d, S)     */
+    BILD_ERR_NOMEM       = 5
+} bild_status;
+
+/* evaluation path, low 4 bits of `flags` of the bild_logl_* calls */
+#define BILD_PATH_AUTO  0u /* modal when the model admits it (symmetric B), else dense    */
+#define BILD_PATH_DENSE 1u /* canonical recursion  C <- B C B + Sig  every frame
+                              (pyx:220-241)                                               */
+#define BILD_PATH_MODAL 2u /* same recursion carried in each state's eigenbasis of B      */
+
+/* bild_model_create flags */
+#define BILD_MODEL_NO_REDUCE 1u /* keep all N modes: skip the invariant-subspace reduction */
+
+typedef struct bild_model   bild_model;
+typedef struct bild_trajset bild_trajset;
+
+int         bild_abi_version(void);
+const char *bild_last_error(void);
+
+/* Number of visible GPUs (0 without a device; never fails on a CPU-only host). */
+int bild_device_count(int *count);
+
+/* ------------------------------------------------------------------ model ----------
+ * Replaces the per-call model setup of the reference kernel
+ * (bild/src/MSRouse_logL.pyx:150-166): measurement vector w, and for each of the S
+ * states the propagator (B, G, Sig) and steady state (M0, C0) that the reference pulls
+ * out of rouse.Model (._dynamics['B'|'G'|'Sig'], .steady_state()).
+ *
+ *   N  monomers, d spatial dimensions (1..3), S states
+ *   B, Sig, C0 : S x N x N     G, M0 : S x N x d     w : N
+ *
+ * Host analysis only (eigenbases for the modal path, packing); no GPU is needed to
+ * create a model.  Device copies are made lazily on the device that is current when an
+ * evaluation first uses the model.  The caller keeps ownership of all inputs.
+ */
+int bild_model_create(int N, int d, int S,
+                      const double *B, const double *G, const double *Sig,
+                      const double *M0, const double *C0, const double *w,
+                      unsigned flags, bild_model **out);
+int bild_model_destroy(bild_model *m);
+
+/* integer properties of a model */
+#define BILD_Q_N            0
+#define BILD_Q_D            1
+#define BILD_Q_S            2
+#define BILD_Q_MODAL_OK     3 /* 1 if the modal path is available                         */
+#define BILD_Q_NP           4 /* padded row count the kernels run with                    */
+#define BILD_Q_NEFF         5 /* modes kept after invariant-subspace reduction            */
+#define BILD_Q_HAS_G        6 /* 1 if any G entry is non-zero                             */
+int bild_model_query(const bild_model *m, int what, int64_t *value);
+
+/* Host-analysis export (for tests that run without a GPU).  `what`:
+ *   BILD_X_LAMBDA : n       eigenvalues of B[s] in the modal basis
+ *   BILD_X_SIGMA  : n       diagonal of Q^T Sig[s] Q
+ *   BILD_X_Q      : Nr x n  modal basis of state s (columns), in reduced coordinates
+ *   BILD_X_WQ     : n       Q^T w
+ *   BILD_X_R      : n x n   basis change  Q[s2]^T Q[s]   (state s -> s2)
+ *   BILD_X_C0Q    : n x n   Q^T C0[s] Q
+ *   BILD_X_V      : N x Nr  reduction basis (identity when no reduction applied)
+ * n = Nr = BILD_Q_NEFF.  `buf` must hold the stated number of doubles. */
+#define BILD_X_LAMBDA 0
+#define BILD_X_SIGMA  1
+#define BILD_X_Q      2
+#define BILD_X_WQ     3
+#define BILD_X_R      4
+#define BILD_X_C0Q    5
+#define BILD_X_V      6
+int bild_model_export(const bild_model *m, int what, int s, int s2, double *buf, int64_t buf_len);
+
+/* ------------------------------------------------------------- trajectories --------
+ * Replaces the per-call trajectory setup (pyx:144-147, 174-178): the (T, d) data with
+ * NaN marking missing frames (a frame is missing iff any coordinate is NaN), and the
+ * per-dimension localization error from which the reference derives
+ * s2 = unique(err)^2 and Cind (np.unique, sorted).
+ *
+ *   n_traj trajectories, lengths T[j] >= 1
+ *   x        : sum(T) x d, trajectories concatenated in order
+ *   loc_err  : n_traj x d, standard deviations (> 0 is not required, >= 0 is)
+ *
+ * Needs a GPU: the data are uploaded once and stay resident for all AMIS steps.
+ */
+int bild_trajset_create(const bild_model *m, int n_traj, const int32_t *T,
+                        const double *x, const double *loc_err, bild_trajset **out);
+int bild_trajset_destroy(bild_trajset *ts);
+
+/* ---------------------------------------------------------------- evaluation -------
+ * One call = one AMIS batch (bild/amis.py:717-739): n independent evaluations
+ * logL(profile_r, traj[traj_id[r]]) -> out[r].
+ *
+ * Profiles come run-length encoded, K1 segments per sample:
+ *   segment i of sample r is in state seg_state[r*K1+i] and starts at frame
+ *   seg_start[r*K1+i]; seg_start[r*K1+0] must be 0 and rows must be non-decreasing.
+ *   Empty segments (equal starts, or a start >= T) are legal and skipped -- this is what
+ *   FixedkSampler.st2profile (bild/amis.py:685-693) produces for
+ *   seg_start[1:] = floor(cumsum(s)[:-1]*(T-1)) + 1, seg_state = theta.
+ *   state[0] selects the steady state the filter starts from, state[t] the propagator
+ *   into frame t (bild/util.py:15-23).
+ *   traj_id may be NULL (all samples refer to trajectory 0).
+ *
+ * All-missing trajectory -> 0.0 (semantics of MSRouse_logL_py.py:90-94).  NaN/Inf in a
+ * result is passed through, never trapped.
+ */
+
+/* host buffers in, host buffer out; synchronous */
+int bild_logl_segments(const bild_model *m, const bild_trajset *ts, int64_t n, int K1,
+                       const int32_t *seg_start, const int32_t *seg_state,
+                       const int32_t *traj_id, unsigned flags, double *out);
+
+/* expanded profiles (MSRouse_logL semantics, pyx:95-98): states is n rows of length
+ * ld >= max T, row r holds T[traj_id[r]] valid entries.  Run-length encoded on the host,
+ * then as above. */
+int bild_logl_profiles(const bild_model *m, const bild_trajset *ts, int64_t n, int64_t ld,
+                       const int32_t *states, const int32_t *traj_id, unsigned flags,
+                       double *out);
+
+/* device buffers in, device buffer out; asynchronous on `hip_stream` (a hipStream_t, or
+ * NULL for the default stream).  This is the entry point timed by bench.py: nothing
+ * crosses PCIe.  d_out must hold n doubles. */
+int bild_logl_segments_device(const bild_model *m, const bild_trajset *ts, int64_t n, int K1,
+                              const int32_t *d_seg_start, const int32_t *d_seg_state,
+                              const int32_t *d_traj_id, unsigned flags, void *hip_stream,
+                              double *d_out);
+
+/* canonical floating-point operations of one batch,
+ *   F = (T-1)(4 N^3 d* + 2 N^2 d) + Tv((4 N^2 + 3 N) d* + 4 N d)      
+ * summed over samples, and the operations the selected path actually executes. */
+int bild_flop_count(const bild_model *m, const bild_trajset *ts, int64_t n,
+                    const int32_t *traj_id /* host, may be NULL */, unsigned flags,
+                    double *canonical, double *executed);
+
+/* name and accumulated device time (ms, HIP events on the launch stream) of the kernel the
+ * most recent evaluations ran; resets the accumulator.  Used by bench.py for the roofline
+ * figure.  Timing is off unless enabled. */
+int bild_kernel_timing(int enable);
+int bild_kernel_timing_read(double *total_ms, int64_t *launches, char *name, int name_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BILD_AMD_H */

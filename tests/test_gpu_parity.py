@@ -1,0 +1,184 @@
+"""
+GPU parity tests (run with -m gpu on an MI355X): the HIP kernels, called through the C ABI,
+against (a) the committed golden vectors of the reference's own kernels and (b) the CPU
+oracle on seeded inputs.
+
+Tolerance: |delta logL| < 1e-8 absolute (BASELINE.json north_star), fp64.
+"""
+import numpy as np
+import pytest
+
+import goldens
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-8
+PATHS = ['modal', 'dense']
+
+
+def _model_from_golden(g, path, reduce=True):
+    import bild_amd
+    m = bild_amd.MultiStateRouse.from_arrays(g['B'], g['G'], g['Sig'], g['M0'], g['C0'], g['w'],
+                                             localization_error=g['localization_error'], path=path)
+    if not reduce:
+        from bild_amd import _lib
+        a = m.arrays()
+        m._handle = _lib.ModelHandle(a['B'], a['G'], a['Sig'], a['M0'], a['C0'], m.measurement, reduce=False)
+    return m
+
+
+def test_native_library_is_loaded(built_lib):
+    from bild_amd import _lib
+    assert _lib.device_count() >= 1
+    with open('/proc/self/maps') as f:
+        assert 'libbild_amd.so' in f.read()
+
+
+@pytest.mark.parametrize('name', goldens.names())
+@pytest.mark.parametrize('path', PATHS)
+@pytest.mark.parametrize('reduce', [True, False])
+def test_goldens(built_lib, name, path, reduce):
+    g = goldens.load(name)
+    m = _model_from_golden(g, path, reduce)
+    got = m.logL_batch(g['states'], g['x'])
+    assert got.shape == (len(g['states']),)
+    for key in ('logL_ref_numpy', 'logL_ref_cython'):
+        ref = g[key]
+        ok = ~np.isnan(ref)
+        if np.any(ok):
+            assert np.max(np.abs(got[ok] - ref[ok])) < TOL, (name, path, key, got, ref)
+    # single-profile entry point (MultiStateModel.logL contract: returns a python float)
+    one = m.logL(H.ProfileView(g['states'][0]), g['x'])
+    assert isinstance(one, float) and abs(one - got[0]) < 1e-12
+
+
+def test_reference_unittest_behaviours(built_lib):
+    """ behavioural pins of reference tests/test_bild.py:135-151 on its own fixture """
+    import bild_amd
+    traj = bild_amd.Trajectory([1, 2, np.nan, 4], localization_error=[0.5])
+    profile = bild_amd.Loopingprofile([1, 1, 0, 0])
+    model = bild_amd.MultiStateRouse(20, 1, 5, d=1)
+    logL = model.logL(profile, traj)
+    assert -100 < logL < 0                                      # :138
+    traj_noerr = bild_amd.Trajectory([1, 2, np.nan, 4])
+    with pytest.raises(ValueError):                             # :140-143
+        model.logL(profile, traj_noerr)
+    model2 = bild_amd.MultiStateRouse(20, 1, 5, d=1, localization_error=0.5)
+    assert model2.logL(profile, traj_noerr) == logL             # :145-148 (identical, not just close)
+
+
+@pytest.mark.parametrize('path', PATHS)
+@pytest.mark.parametrize('S,T,k,miss', [(2, 200, 2, 'none'), (2, 333, 5, 'iid'), (3, 400, 4, 'bursty'), (2, 97, 0, 'none')])
+def test_sampler_batch_vs_oracle(built_lib, path, S, T, k, miss):
+    """ FixedkSampler.logL(ss, thetas) == oracle on the st2profile-expanded profiles """
+    import bild_amd
+    from oracle import oracle
+    rng = np.random.default_rng(100 * S + T + k)
+    model = bild_amd.MultiStateRouse(20, 1, 5, d=3, looppositions=H.LOOPS[S], localization_error=0.1, path=path)
+    truth = H.random_profile(rng, T, S, max(T // 5, 2))
+    traj = model.trajectory_from_loopingprofile(truth, missing_frames=H.missing_mask(rng, T, miss), rng=rng)
+    n = 300
+    ss, thetas = H.candidate_profiles(rng, n, k, S)
+    sampler = bild_amd.FixedkSampler(traj, model, k=k, N=n)
+    got = sampler.logL(ss, thetas)
+    states = H.expand(ss, thetas, T)
+    # the sampler's own st2profile must agree with the batch encoding
+    assert np.array_equal(sampler.st2profile(ss[7], thetas[7])[:], states[7])
+    want = oracle.logl_batch(model.arrays(), model.measurement, model.localization_error, traj[:], states)
+    assert got.dtype == np.float64 and got.shape == (n,)
+    assert np.max(np.abs(got - want)) < TOL
+
+
+@pytest.mark.parametrize('N', [2, 4, 7, 8, 16, 20, 31, 32])
+def test_chain_lengths(built_lib, N):
+    import bild_amd
+    from oracle import oracle
+    rng = np.random.default_rng(N)
+    T = 120
+    for reduce in (True, False):
+        model = bild_amd.MultiStateRouse(N, 1, 2, d=2, localization_error=[0.1, 0.2])
+        if not reduce:
+            from bild_amd import _lib
+            a = model.arrays()
+            model._handle = _lib.ModelHandle(a['B'], a['G'], a['Sig'], a['M0'], a['C0'], model.measurement, reduce=False)
+        truth = H.random_profile(rng, T, 2, 30)
+        traj = model.trajectory_from_loopingprofile(truth, missing_frames=0.1, rng=rng)
+        ss, thetas = H.candidate_profiles(rng, 40, 3, 2)
+        states = H.expand(ss, thetas, T)
+        want = oracle.logl_batch(model.arrays(), model.measurement, model.localization_error, traj[:], states)
+        for path in PATHS:
+            model.path = path
+            got = model.logL_st_batch(ss, thetas, traj)
+            assert np.max(np.abs(got - want)) < TOL, (N, reduce, path)
+
+
+def test_multi_trajectory_batch(built_lib):
+    """ samples spread over several trajectories of different length / noise / masks """
+    import bild_amd
+    from oracle import oracle
+    from bild_amd.profiles import segments_from_st
+    rng = np.random.default_rng(5)
+    model = bild_amd.MultiStateRouse(20, 1, 5, d=3)
+    trajs, seg_start, seg_state, tid, want = [], [], [], [], []
+    K = 4
+    for j, (T, err) in enumerate([(150, 0.1), (90, [0.1, 0.1, 0.3]), (211, 0.05), (64, [0.2, 0.1, 0.05])]):
+        truth = H.random_profile(rng, T, 2, 40)
+        tr = model.trajectory_from_loopingprofile(truth, localization_error=err, missing_frames=0.05 * j, rng=rng)
+        trajs.append(tr)
+        ss, thetas = H.candidate_profiles(rng, 25, K, 2)
+        a, b = segments_from_st(ss, thetas, T)
+        seg_start.append(a)
+        seg_state.append(b)
+        tid += [j] * 25
+        want.append(oracle.logl_batch(model.arrays(), model.measurement, tr.localization_error, tr[:], H.expand(ss, thetas, T)))
+    perm = rng.permutation(100)
+    seg_start = np.concatenate(seg_start)[perm]
+    seg_state = np.concatenate(seg_state)[perm]
+    tid = np.asarray(tid)[perm]
+    want = np.concatenate(want)[perm]
+    for path in PATHS:
+        model.path = path
+        got = model.logL_segments(seg_start, seg_state, trajs, tid)
+        assert np.max(np.abs(got - want)) < TOL
+
+
+def test_full_size_properties(built_lib):
+    """
+    BASELINE configs[1] size (10k samples x T=1000): properties that do not need the oracle
+    at full size -- both kernel paths agree, permutation equivariance, and a 64-sample
+    spot check against the oracle.
+    """
+    import bild_amd
+    from oracle import oracle
+    rng = np.random.default_rng(42)
+    T, n, k = 1000, 10000, 4
+    model = bild_amd.MultiStateRouse(20, 1, 5, d=3, localization_error=0.1)
+    truth = H.random_profile(rng, T, 2, 200)
+    traj = model.trajectory_from_loopingprofile(truth, rng=rng)
+    ss, thetas = H.candidate_profiles(rng, n, k, 2)
+    model.path = 'modal'
+    a = model.logL_st_batch(ss, thetas, traj)
+    model.path = 'dense'
+    b = model.logL_st_batch(ss, thetas, traj)
+    assert np.all(np.isfinite(a)) and np.max(np.abs(a - b)) < TOL
+    perm = rng.permutation(n)
+    model.path = 'modal'
+    c = model.logL_st_batch(ss[perm], thetas[perm], traj)
+    assert np.array_equal(c, a[perm])          # bit-identical regardless of placement in the batch
+    pick = rng.choice(n, 64, replace=False)
+    want = oracle.logl_batch(model.arrays(), model.measurement, model.localization_error, traj[:],
+                             H.expand(ss[pick], thetas[pick], T))
+    assert np.max(np.abs(a[pick] - want)) < TOL
+
+
+def test_error_paths(built_lib):
+    import bild_amd
+    from bild_amd import _lib
+    model = bild_amd.MultiStateRouse(8, 1, 2, d=2, localization_error=0.1)
+    traj = bild_amd.Trajectory(np.zeros((10, 2)))
+    with pytest.raises(_lib.BildAmdError):     # state index out of range
+        model.logL_batch(np.full((1, 10), 5), traj)
+    with pytest.raises(AssertionError):        # wrong spatial dimension (reference asserts shapes, pyx:165-166)
+        model.logL_batch(np.zeros((1, 10), int), bild_amd.Trajectory(np.zeros((10, 3))))
+    assert model.logL_batch(np.zeros((0, 10), int), traj).shape == (0,)
