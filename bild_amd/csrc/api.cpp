@@ -106,7 +106,7 @@ struct bild_model {
     std::string modal_why;
     Mat lam, sigd, Q, wq, R, C0q, M0q, Gq; // S*n, S*n, S*n*n, S*n, S*S*n*n, S*n*n, S*n*d, S*n*d
     // packed for the kernels
-    Geometry geom{0, 0, 0};
+    Geometry geom{0, 0, 0, 0};
     Mat blob_states[2], blob_tab[2];
     // device residency
     mutable std::mutex mu;
@@ -423,8 +423,8 @@ size_t lds_bytes(const bild_model &m, int mode)
 {
     // dense: propagator tables + per-group product images; modal: product images only (the
     // basis-change matrices are read through L2, they are touched only at state switches)
-    const size_t groups = (size_t)kWaves * (64 / m.geom.G);
-    const size_t image = (size_t)m.geom.CPL * m.geom.G * m.geom.NP;
+    const size_t groups = (size_t)m.geom.W * (64 / m.geom.G);
+    const size_t image = (size_t)group_image_doubles(m.geom.NP);
     return ((mode == kDense ? m.blob_tab[mode].size() : 0) + groups * image) * sizeof(double);
 }
 
@@ -493,7 +493,7 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
     p.out = target;
 
     const int gpw = 64 / m.geom.G;
-    const int64_t tasks_per_block = (int64_t)kWaves * gpw;
+    const int64_t tasks_per_block = (int64_t)m.geom.W * gpw;
     int64_t blocks = (p.ntasks + tasks_per_block - 1) / tasks_per_block;
     const int grid = (int)std::min<int64_t>(std::max<int64_t>(blocks, 1), 256 * 16);
 

@@ -5,8 +5,7 @@
 namespace bild {
 
 constexpr int kDMax = 3;      // spatial dimensions supported (reference default d = 3, models.py:222)
-constexpr int kThreads = 256; // threads per workgroup = 4 wavefronts of 64
-constexpr int kWaves = kThreads / 64;
+constexpr int kMaxWaves = 4;  // wavefronts per workgroup (fewer for long chains: LDS capacity)
 constexpr int kMaxNP = 32;    // largest padded chain length with a compiled kernel
 
 enum Mode : int { kDense = 0, kModal = 1 };
@@ -59,8 +58,12 @@ struct KParams {
 
 // launch geometry for a padded chain length
 struct Geometry {
-    int NP, CPL, G;
+    int NP, CPL, G; // padded rows, columns per lane, lanes per group
+    int W;          // wavefronts per workgroup
 };
+
+// doubles of LDS one group needs: image of X*[C|M], NP+kDMax columns of NP rows
+constexpr int group_image_doubles(int NP) { return (NP + kDMax) * NP; }
 
 // host-callable launchers implemented in kernels.hip
 int launch_logl(const Geometry &g, int mode, const KParams &p, int grid, size_t lds_bytes, void *stream);

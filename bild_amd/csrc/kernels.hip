@@ -63,7 +63,7 @@ struct Cols {
 // propagators, global/L2 for the modal basis changes); one X operand feeds CPL FMAs.
 template <int NP, int CPL, typename XPtr>
 __device__ __forceinline__ void matvec_to_lds(XPtr X, const Cols<NP, CPL> &in, double *__restrict__ Tg,
-                                              const int (&cidx)[CPL])
+                                              const int (&cidx)[CPL], const bool (&store)[CPL])
 {
 #pragma unroll 1
     for (int i = 0; i < NP; i += 2) {
@@ -84,13 +84,15 @@ __device__ __forceinline__ void matvec_to_lds(XPtr X, const Cols<NP, CPL> &in, d
         }
 #pragma unroll
         for (int q = 0; q < CPL; ++q)
-            *reinterpret_cast<double2 *>(Tg + cidx[q] * NP + i) = make_double2(a0[q], a1[q]);
+            if (store[q]) *reinterpret_cast<double2 *>(Tg + cidx[q] * NP + i) = make_double2(a0[q], a1[q]);
     }
 }
 
-template <int NP, int CPL, int G, int MODE>
-__global__ void __launch_bounds__(kThreads) logl_kernel(const KParams p)
+template <int NP, int CPL, int G, int W, int MODE>
+__global__ void __launch_bounds__(64 * W) logl_kernel(const KParams p)
 {
+    constexpr int kThreads = 64 * W;
+    constexpr int kWaves = W;
     constexpr int GPW = 64 / G;          // groups (= tasks in flight) per wavefront
     constexpr int MS = table_stride(NP); // LDS matrix stride
     constexpr int SB = StateBlock::size(NP);
@@ -110,18 +112,18 @@ __global__ void __launch_bounds__(kThreads) logl_kernel(const KParams p)
         for (int i = tid; i < p.tab_doubles; i += kThreads) smem[i] = p.tab[i];
         __syncthreads();
     }
-    // per-group scratch: image of X*A, NC columns of NP doubles; its first NP doubles double as
-    // the all-gather buffer of the update
-    constexpr int NC = CPL * G;
+    // per-group scratch: image of X*A, NP + kDMax columns of NP doubles; its first NP doubles
+    // double as the all-gather buffer of the update
     const int lds_tab = (MODE == kDense) ? p.tab_doubles : 0;
-    double *const scratch = smem + lds_tab + (size_t)(wv * GPW + grp) * (NC * NP);
+    double *const scratch = smem + lds_tab + (size_t)(wv * GPW + grp) * group_image_doubles(NP);
 
     int cidx[CPL];
-    bool isC[CPL];
+    bool isC[CPL], hasImg[CPL];
 #pragma unroll
     for (int q = 0; q < CPL; ++q) {
         cidx[q] = gl * CPL + q;
         isC[q] = cidx[q] < NP;
+        hasImg[q] = cidx[q] < NP + kDMax; // spare columns have no LDS image (and stay zero)
     }
 
     const int S = p.S;
@@ -259,18 +261,20 @@ __global__ void __launch_bounds__(kThreads) logl_kernel(const KParams p)
         // modal basis change (X = R).  `after_left` runs on the mean columns between the
         // two multiplies (adds G in the dense predict).
         auto sandwich = [&](auto X, auto &&after_left) {
-            matvec_to_lds<NP, CPL>(X, col, scratch, cidx);
+            matvec_to_lds<NP, CPL>(X, col, scratch, cidx, hasImg);
             wave_lds_fence();
 #pragma unroll
             for (int q = 0; q < CPL; ++q) {
-                const int c = cidx[q] < NP ? cidx[q] : cidx[q] * NP; // covariance: walk row c; mean: own column
-                const int st = cidx[q] < NP ? NP : 1;
+                // covariance: walk row c of the image; mean: own column; spare: anything in range
+                const int c = isC[q] ? cidx[q] : (hasImg[q] ? cidx[q] * NP : 0);
+                const int st = isC[q] ? NP : 1;
+                const double keep = hasImg[q] ? 1.0 : 0.0;
 #pragma unroll
-                for (int i = 0; i < NP; ++i) col.v[q][i] = scratch[c + i * st];
+                for (int i = 0; i < NP; ++i) col.v[q][i] = keep * scratch[c + i * st];
             }
             wave_lds_fence();
             after_left();
-            matvec_to_lds<NP, CPL>(X, col, scratch, cidx);
+            matvec_to_lds<NP, CPL>(X, col, scratch, cidx, isC);
             wave_lds_fence();
 #pragma unroll
             for (int q = 0; q < CPL; ++q)
@@ -384,17 +388,18 @@ __global__ void reduce_partials_kernel(const double *__restrict__ partial, doubl
     out[r] = tot;
 }
 
-template <int NP, int CPL, int G>
+template <int NP, int CPL, int G, int W>
 int launch_geom(int mode, const KParams &p, int grid, size_t lds, hipStream_t st)
 {
+    constexpr int kThreads = 64 * W;
     hipError_t err;
     if (mode == kModal) {
-        auto k = logl_kernel<NP, CPL, G, kModal>;
+        auto k = logl_kernel<NP, CPL, G, W, kModal>;
         err = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess) return (int)err;
         hipLaunchKernelGGL(k, dim3(grid), dim3(kThreads), lds, st, p);
     } else {
-        auto k = logl_kernel<NP, CPL, G, kDense>;
+        auto k = logl_kernel<NP, CPL, G, W, kDense>;
         err = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess) return (int)err;
         hipLaunchKernelGGL(k, dim3(grid), dim3(kThreads), lds, st, p);
@@ -402,9 +407,23 @@ int launch_geom(int mode, const KParams &p, int grid, size_t lds, hipStream_t st
     return (int)hipGetLastError();
 }
 
-// (rows, columns-per-lane, lanes-per-group); CPL * G >= NP + 3
+// (rows, columns per lane, lanes per group, waves per workgroup); CPL * G >= NP + 3.
+// W is chosen so that W * (64/G) group images + the dense tables fit in 160 KiB of LDS.
+#define BILD_GEOMETRIES(X) \
+    X(4, 1, 8, 4)          \
+    X(8, 3, 4, 4)          \
+    X(10, 2, 8, 4)         \
+    X(12, 2, 8, 4)         \
+    X(16, 3, 8, 4)         \
+    X(20, 3, 8, 4)         \
+    X(24, 4, 8, 2)         \
+    X(28, 4, 8, 2)         \
+    X(32, 3, 16, 2)
+
 constexpr Geometry kGeoms[] = {
-    {4, 1, 8}, {8, 3, 4}, {12, 2, 8}, {16, 3, 8}, {20, 3, 8}, {24, 4, 8}, {28, 4, 8}, {32, 3, 16},
+#define X(NP, CPL, G, W) {NP, CPL, G, W},
+    BILD_GEOMETRIES(X)
+#undef X
 };
 
 } // namespace
@@ -425,18 +444,10 @@ int launch_logl(const Geometry &g, int mode, const KParams &p, int grid, size_t 
 {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     switch (g.NP) {
-#ifndef BILD_ONLY_NP20
-    case 4: return launch_geom<4, 1, 8>(mode, p, grid, lds, st);
-    case 8: return launch_geom<8, 3, 4>(mode, p, grid, lds, st);
-    case 12: return launch_geom<12, 2, 8>(mode, p, grid, lds, st);
-    case 16: return launch_geom<16, 3, 8>(mode, p, grid, lds, st);
-#endif
-    case 20: return launch_geom<20, 3, 8>(mode, p, grid, lds, st);
-#ifndef BILD_ONLY_NP20
-    case 24: return launch_geom<24, 4, 8>(mode, p, grid, lds, st);
-    case 28: return launch_geom<28, 4, 8>(mode, p, grid, lds, st);
-    case 32: return launch_geom<32, 3, 16>(mode, p, grid, lds, st);
-#endif
+#define X(NP, CPL, G, W) \
+    case NP: return launch_geom<NP, CPL, G, W>(mode, p, grid, lds, st);
+        BILD_GEOMETRIES(X)
+#undef X
     default: return -1;
     }
 }

@@ -1,0 +1,67 @@
+"""
+Multi-GPU sharding of an AMIS batch: one process per GPU (``torch.distributed``; backend
+"nccl" is RCCL on ROCm, "gloo" on CPU for tests).
+
+The evaluations of a batch are independent (reference bild/amis.py:735-739 loops over them
+in arbitrary order), so the batch is split into contiguous shards with no data-path
+communication.  The one exchange an AMIS step needs is the vector of log-likelihoods itself
+-- every rank forms the importance weights ``logLs - log_delta + log(n_steps)``
+(bild/amis.py:843-845) from the full vector -- i.e. a single all-gather of float64[n_local]
+per step.  Messages are tiny (80 KB per 10k batch): the collective is latency-bound, so it
+is issued once per step on the full shard, never per sample or per trajectory.
+"""
+import numpy as np
+
+
+def shard_bounds(n, world, rank):
+    """ contiguous, balanced split of range(n): sizes differ by at most one """
+    base, rem = divmod(int(n), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_by_trajectory(T_per_traj, n_per_traj, world):
+    """
+    Assign whole trajectories to ranks (keeps one trajectory's data and missing-frame branch
+    pattern on one device), balancing the cost model T * n_samples greedily.
+
+    Returns a list of index arrays, one per rank.
+    """
+    cost = np.asarray(T_per_traj, dtype=np.float64) * np.asarray(n_per_traj, dtype=np.float64)
+    order = np.argsort(-cost, kind='stable')
+    load = np.zeros(world)
+    owner = [[] for _ in range(world)]
+    for j in order:
+        r = int(np.argmin(load))
+        owner[r].append(int(j))
+        load[r] += cost[j]
+    return [np.array(sorted(o), dtype=np.int64) for o in owner]
+
+
+def all_gather_logl(local, out=None, group=None):
+    """
+    All-gather equally sized shards of log-likelihoods (torch tensors on the backend's device).
+    """
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    if out is None:
+        out = torch.empty(local.numel() * world, dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+    return out
+
+
+def all_gather_logl_ragged(local, sizes, group=None):
+    """
+    All-gather shards of different length (``sizes[r]`` entries on rank r): padded to the
+    longest shard so that a single collective suffices, then compacted.
+    """
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    m = int(max(sizes))
+    pad = torch.zeros(m, dtype=local.dtype, device=local.device)
+    pad[:local.numel()] = local
+    buf = torch.empty(m * world, dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(buf, pad, group=group)
+    return torch.cat([buf[r * m:r * m + int(sizes[r])] for r in range(world)])
