@@ -1,0 +1,146 @@
+"""
+CPU tests of the boundary: the C-ABI library loads without a GPU, exports every symbol
+declared in include/bild_amd.h, and its host-side model analysis (invariant-subspace
+reduction, modal decomposition) is mathematically consistent.  No compute calls here.
+"""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import goldens
+import helpers as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_exported(built_lib):
+    header = open(os.path.join(ROOT, 'include', 'bild_amd.h')).read()
+    declared = set(re.findall(r'\b(bild_[a-z_]+)\s*\(', header))
+    assert len(declared) >= 14
+    for name in declared:
+        assert hasattr(built_lib, name), f"{name} declared in include/bild_amd.h but not exported"
+    from bild_amd import _lib
+    assert declared == set(_lib.exported_symbols())
+    assert built_lib.bild_abi_version() == 1
+
+
+def test_loads_without_gpu_and_fails_loudly(built_lib):
+    import bild_amd
+    from bild_amd import _lib
+    if _lib.device_count() > 0:
+        pytest.skip("GPU present")
+    model = bild_amd.MultiStateRouse(20, 1, 5, d=1)
+    traj = bild_amd.Trajectory([1, 2, np.nan, 4], localization_error=[0.5])
+    with pytest.raises(_lib.NoDeviceError):      # no CPU fallback, ever
+        model.logL(bild_amd.Loopingprofile([1, 1, 0, 0]), traj)
+
+
+def test_no_localization_error_is_valueerror(built_lib):
+    # reference bild/models.py:263, tested at tests/test_bild.py:140-143 -- raised before any device work
+    import bild_amd
+    model = bild_amd.MultiStateRouse(20, 1, 5, d=1)
+    with pytest.raises(ValueError):
+        model.logL(bild_amd.Loopingprofile([1, 1, 0, 0]), bild_amd.Trajectory([1, 2, np.nan, 4]))
+
+
+def test_model_argument_validation(built_lib):
+    from bild_amd import _lib
+    a = H.DuckModel(N=6, d=2).arrays()
+    w = H.end2end(6)
+    with pytest.raises(AssertionError):
+        _lib.ModelHandle(a['B'], a['G'], a['Sig'], a['M0'], a['C0'], w[:-1])
+    bad = a['B'].copy()
+    bad[0, 0, 0] = np.nan
+    with pytest.raises(_lib.BildAmdError):
+        _lib.ModelHandle(bad, a['G'], a['Sig'], a['M0'], a['C0'], w)
+    with pytest.raises(_lib.BildAmdError):        # d = 4 is outside the compiled envelope
+        _lib.ModelHandle(a['B'], np.zeros((2, 6, 4)), a['Sig'], np.zeros((2, 6, 4)), a['C0'], w)
+
+
+@pytest.mark.parametrize('N,loops,expect', [
+    (20, H.LOOPS[2], 10),        # reflection-antisymmetric half
+    (21, H.LOOPS[2], 10),
+    (8, H.LOOPS[2], 4),
+    (20, H.LOOPS[3], None),      # (0, 10) bond breaks the reflection symmetry: fewer modes decouple
+    (12, (None, (1, 7)), None),
+])
+def test_invariant_subspace_reduction(built_lib, N, loops, expect):
+    from bild_amd import _lib
+    dm = H.DuckModel(N=N, loops=loops)
+    a, w = dm.arrays(), dm.measurement
+    h = _lib.ModelHandle(a['B'], a['G'], a['Sig'], a['M0'], a['C0'], w)
+    n = h.query(_lib.Q_NEFF)
+    if expect is not None:
+        assert n == expect
+    assert 1 <= n <= N
+    V = h.export(_lib.X_V)
+    assert np.max(np.abs(V.T @ V - np.eye(n))) < 1e-13
+    assert np.max(np.abs(V @ (V.T @ w) - w)) < 1e-13          # w lies in the subspace
+    for key in ('B', 'Sig', 'C0'):
+        for X in a[key]:
+            assert np.max(np.abs(X @ V - V @ (V.T @ X @ V))) < 1e-12 * max(1., np.abs(X).max())  # invariant
+    h_full = _lib.ModelHandle(a['B'], a['G'], a['Sig'], a['M0'], a['C0'], w, reduce=False)
+    assert h_full.query(_lib.Q_NEFF) == N
+
+
+def _modal_filter_numpy(h, S, x, states, err):
+    """ the modal algorithm the kernel implements, in NumPy, from the library's own host analysis """
+    from bild_amd import _lib as L
+    n = h.query(L.Q_NEFF)
+    lam = [h.export(L.X_LAMBDA, s) for s in range(S)]
+    sig = [h.export(L.X_SIGMA, s) for s in range(S)]
+    wq = [h.export(L.X_WQ, s) for s in range(S)]
+    C0q = [h.export(L.X_C0Q, s) for s in range(S)]
+    R = {(a, b): h.export(L.X_R, a, b) for a in range(S) for b in range(S)}
+    s = states[0]
+    C, M, tot, s2 = C0q[s].copy(), np.zeros((n, x.shape[1])), 0., err ** 2
+    for t in range(len(states)):
+        if t > 0:
+            sn = states[t]
+            if sn != s:
+                Rm = R[(s, sn)]
+                C, M, s = Rm @ C @ Rm.T, Rm @ M, sn
+            C = np.outer(lam[s], lam[s]) * C + np.diag(sig[s])
+            M = lam[s][:, None] * M
+        if not np.isnan(x[t]).any():
+            Cw = C @ wq[s]
+            Sv = wq[s] @ Cw + s2
+            nu = x[t] - wq[s] @ M
+            C = C - np.outer(Cw, Cw) / Sv
+            M = M + np.outer(Cw, nu) / Sv
+            tot += np.sum(-0.5 * (nu * nu / Sv + np.log(Sv) + np.log(2 * np.pi)))
+    return tot
+
+
+@pytest.mark.parametrize('name', ['s2_d3_T200', 's3_bursty_T300', 'asym_w_partial_nan_T60'])
+@pytest.mark.parametrize('reduce', [True, False])
+def test_host_analysis_reproduces_reference(built_lib, name, reduce):
+    """ reduction + eigenbases exported by the library, run through a NumPy filter, hit the reference goldens """
+    from bild_amd import _lib
+    g = goldens.load(name)
+    h = _lib.ModelHandle(g['B'], g['G'], g['Sig'], g['M0'], g['C0'], g['w'], reduce=reduce)
+    assert h.query(_lib.Q_MODAL_OK) == 1
+    S = g['B'].shape[0]
+    for s in range(S):
+        Q, lam, V = h.export(_lib.X_Q, s), h.export(_lib.X_LAMBDA, s), h.export(_lib.X_V)
+        assert np.max(np.abs(Q.T @ Q - np.eye(len(lam)))) < 1e-13
+        assert np.max(np.abs(Q @ np.diag(lam) @ Q.T - V.T @ g['B'][s] @ V)) < 1e-13
+    err = g['localization_error']
+    assert np.all(err == err[0])
+    for i in range(min(4, len(g['states']))):
+        got = _modal_filter_numpy(h, S, g['x'], g['states'][i], err[0])
+        assert abs(got - g['logL_ref_cython'][i]) < 1e-8
+        assert abs(got - g['logL_ref_numpy'][i]) < 1e-8
+
+
+def test_modal_unavailable_for_nonsymmetric_propagator(built_lib):
+    from bild_amd import _lib
+    a = H.DuckModel(N=6, d=2).arrays()
+    B = a['B'].copy()
+    B[0, 0, 1] += 0.01      # the reference's two kernels already disagree on such input (dsymv vs full matmul)
+    h = _lib.ModelHandle(B, a['G'], a['Sig'], a['M0'], a['C0'], H.end2end(6))
+    assert h.query(_lib.Q_MODAL_OK) == 0 and h.query(_lib.Q_NEFF) == 6
+    with pytest.raises(_lib.BildAmdError):
+        h.export(_lib.X_Q, 0)

@@ -1,0 +1,77 @@
+"""
+CPU tests of the host-side profile logic: Loopingprofile (pins of reference
+tests/test_bild.py:51-121) and the (s, theta) -> switch-index encoding (pins of reference
+tests/test_amis.py:199-202 and the slice semantics of bild/amis.py:685-693).
+"""
+import numpy as np
+
+import helpers as H
+from bild_amd.profiles import (Loopingprofile, state_probabilities, switch_indices, segments_from_st,
+                               segments_from_states, states_from_segments)
+from bild_amd.amis import FixedkSampler
+
+
+def test_loopingprofile_basics():
+    p = Loopingprofile([0, 0, 0, 1, 1, 0])
+    assert len(p) == 6 and p[3] == 1 and p.count_switches() == 2
+    q = p.copy()
+    assert q == p
+    q[0] = 1
+    assert not (q == p) and p[0] == 0
+    assert p.intervals() == [(None, 3, 0), (3, 5, 1), (5, None, 0)]
+    t, y = p.plottable()
+    assert np.array_equal(t, [-1, 2, 2, 4, 4, 5]) and np.array_equal(y, [0, 0, 1, 1, 0, 0])
+    try:
+        p[0] = 1.5
+        raise RuntimeError("float assignment must be rejected")
+    except AssertionError:
+        pass
+    assert not (p == Loopingprofile([0, 0]))
+
+
+def test_state_probabilities():
+    profs = [Loopingprofile([0, 0, 1]), Loopingprofile([0, 1, 1])]
+    pr = state_probabilities(profs)
+    assert np.allclose(pr, [[1, .5, 0], [0, .5, 1]])
+    assert state_probabilities(profs, nStates=3).shape == (3, 3)
+
+
+class _FakeModel:
+    nStates = 2
+
+
+def test_st2profile_reference_pin():
+    # reference tests/test_amis.py:199-202: st2profile([.25,.5,.25],[0,1,0]) on T=6 -> [0,0,1,1,0,0]
+    sampler = FixedkSampler(np.zeros((6, 1)), _FakeModel(), k=2)
+    prof = sampler.st2profile(np.array([0.25, 0.5, 0.25]), np.array([0, 1, 0]))
+    assert np.array_equal(prof[:], [0, 0, 1, 1, 0, 0])
+    assert isinstance(prof, Loopingprofile) and prof.state.dtype.kind == 'i'
+
+
+def test_segments_match_st2profile_semantics():
+    rng = np.random.default_rng(0)
+    for T in (2, 5, 37, 200):
+        for k in (0, 1, 3, 7):
+            ss, thetas = H.candidate_profiles(rng, 50, k, 3)
+            # force degenerate cases: zero-length intervals and a cumsum that reaches 1.0 early
+            ss[0, :] = 0
+            ss[0, 0] = 1.0
+            if k >= 2:
+                ss[1, 1] = 0.0
+                ss[1] /= ss[1].sum()
+            sampler = FixedkSampler(np.zeros((T, 1)), _FakeModel(), k=k)
+            seg_start, seg_state = segments_from_st(ss, thetas, T)
+            assert seg_start.dtype == np.int32 and np.all(seg_start[:, 0] == 0)
+            assert np.all(np.diff(seg_start, axis=1) >= 0) and np.all(seg_start[:, 1:] >= 1)
+            exp = states_from_segments(seg_start, seg_state, T)
+            for r in range(len(ss)):
+                assert np.array_equal(sampler.st2profile(ss[r], thetas[r])[:], exp[r])
+            # run-length encoding of the expanded profiles gives the same profiles back
+            a, b = segments_from_states(exp)
+            assert np.array_equal(states_from_segments(a, b, T), exp)
+
+
+def test_switch_indices_formula():
+    ss = np.array([[0.25, 0.5, 0.25], [0.0, 0.0, 1.0], [1.0, 0.0, 0.0]])
+    assert np.array_equal(switch_indices(ss, 6), [[2, 4], [1, 1], [6, 6]])
+    assert switch_indices(np.ones((4, 1)), 10).shape == (4, 0)
