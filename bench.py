@@ -95,6 +95,11 @@ def main():
     ap.add_argument('--path', default='auto', choices=['auto', 'modal', 'dense'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-dense', action='store_true', help='skip the secondary dense-path measurement')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help="collective backend; 'gloo' (log-likelihoods staged through host memory) rehearses the "
+                         "multi-rank path on a box with fewer GPUs than ranks")
+    ap.add_argument('--host-buffers', action='store_true',
+                    help='also time the host-buffer entry point (H2D of the profiles + D2H of the results per step)')
     args = ap.parse_args()
 
     import torch
@@ -110,9 +115,16 @@ def main():
         raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     if rank == 0:
         entry.build()
-    torch.cuda.set_device(local_rank)
+    n_dev = torch.cuda.device_count()
+    if args.backend == 'nccl' and world > n_dev:
+        raise SystemExit(f"{world} ranks but {n_dev} GPUs (use --backend gloo to rehearse)")
+    dev_index = local_rank % max(n_dev, 1)
+    torch.cuda.set_device(dev_index)
     if world > 1:
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', dev_index))
+        else:
+            dist.init_process_group('gloo')
         dist.barrier()
 
     from bild_amd import _lib
@@ -125,7 +137,7 @@ def main():
     h = model.handle()
     ts = model.trajset(traj)                          # trajectory resident in HBM
     seg_start, seg_state = segments_from_st(ss, thetas, T)
-    dev = torch.device('cuda', local_rank)
+    dev = torch.device('cuda', dev_index)
     d_start = torch.from_numpy(seg_start).to(dev)     # candidates resident in HBM
     d_state = torch.from_numpy(seg_state).to(dev)
     d_out = torch.empty(n, dtype=torch.float64, device=dev)
@@ -135,8 +147,11 @@ def main():
         stream = torch.cuda.current_stream().cuda_stream
         _lib.logl_segments_device(h, ts, n, k + 1, d_start.data_ptr(), d_state.data_ptr(), 0, d_out.data_ptr(),
                                   stream=stream, path=path)
-        if world > 1:
-            bdist.all_gather_logl(d_out, d_all)       # the one collective of an AMIS step
+        if world > 1:                                 # the one collective of an AMIS step
+            if args.backend == 'nccl':
+                bdist.all_gather_logl(d_out, d_all)
+            else:
+                d_all.copy_(bdist.all_gather_logl(d_out.cpu()))
 
     def timed(path, steps, warmup):
         for _ in range(warmup):
@@ -155,7 +170,7 @@ def main():
         _lib.kernel_timing(False)
         kms, launches, kname = _lib.kernel_timing_read()
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == 'nccl' else 'cpu')
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt, kms / max(launches, 1), kname
@@ -194,7 +209,7 @@ def main():
         'config': {'workload': f'configs[1]: {n} profile samples x 1 trajectory per GPU, T={T}, {args.states}-state '
                                f'Rouse N=20 d=3 d*=1, k={k} switches, fp64',
                    'samples_per_gpu': n, 'T': T, 'k': k, 'states': args.states, 'path': args.path,
-                   'collective': 'all_gather(float64[%d]) per step' % n if world > 1 else 'none (1 GPU)'},
+                   'collective': ('all_gather(float64[%d]) per step, %s' % (n, args.backend)) if world > 1 else 'none (1 GPU)'},
         'roofline': roofline,
     }
 
@@ -207,6 +222,16 @@ def main():
                 'achieved': dcan / (dkms * 1e-3) / 1e12, 'frac': dcan / (dkms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                 'executed_frac': dexe / (dkms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
             }
+        if args.host_buffers:
+            # PCIe-inclusive rate of the synchronous host entry point (never `value`)
+            for _ in range(2):
+                _lib.logl_segments(h, ts, seg_start, seg_state, path=args.path)
+            t0 = time.perf_counter()
+            reps = max(5, args.steps // 2)
+            for _ in range(reps):
+                _lib.logl_segments(h, ts, seg_start, seg_state, path=args.path)
+            result['host_buffers'] = {'value': n * reps / (time.perf_counter() - t0), 'unit': 'evals/s',
+                                      'note': 'bild_logl_segments: H2D profiles + launch + D2H results + sync per step'}
         if not args.no_cpu_baseline:
             base, ref_out = cpu_baseline(model, traj, ss, thetas, T)
             result['cpu_baseline'] = base

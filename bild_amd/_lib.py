@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libbild_amd.so')
+# BILD_AMD_LIB selects an alternative build of the same ABI (kernel A/B experiments, tools/ab.py)
+LIB_PATH = os.environ.get('BILD_AMD_LIB') or os.path.join(_HERE, 'libbild_amd.so')
 
 OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_NOMEM = range(6)
 

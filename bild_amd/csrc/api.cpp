@@ -124,9 +124,11 @@ struct bild_trajset {
     int dstar_max = 1;
     int Tmax = 0;
     int device = -1;
-    double *d_x = nullptr;
+    double *d_x = nullptr; // all trajectories, each followed by one padding row, then kZeroPad zeros
+    double *d_zeros = nullptr;
     TrajDesc *d_descs = nullptr;
 };
+constexpr int kZeroPad = 8;
 
 namespace {
 
@@ -483,6 +485,7 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
     p.seg_start = d_seg_start;
     p.seg_state = d_seg_state;
     p.traj_id = d_traj_id;
+    p.zeros = ts.d_zeros;
     double *target = d_out;
     if (ts.dstar_max > 1) {
         std::lock_guard<std::mutex> lk(m.mu);
@@ -661,7 +664,8 @@ int bild_trajset_create(const bild_model *m, int n_traj, const int32_t *T, const
     ts->descs.resize(n_traj);
 
     // device copy of the data: a frame with any NaN coordinate is missing (pyx:178) -> all NaN
-    std::vector<double> xd((size_t)total * d);
+    // layout: per trajectory T rows + 1 padding row (the kernels fetch one frame ahead), then zeros
+    std::vector<double> xd((size_t)(total + n_traj) * d + kZeroPad, 0.0);
     const double qnan = std::nan("");
     int64_t off = 0;
     auto cleanup = [&](int code) {
@@ -670,18 +674,20 @@ int bild_trajset_create(const bild_model *m, int n_traj, const int32_t *T, const
         delete ts;
         return code;
     };
-    hipError_t he = hipMalloc((void **)&ts->d_x, std::max<size_t>(xd.size(), 1) * sizeof(double));
+    hipError_t he = hipMalloc((void **)&ts->d_x, xd.size() * sizeof(double));
     if (he != hipSuccess) return cleanup(fail(BILD_ERR_NOMEM, "hipMalloc failed: %s", hipGetErrorString(he)));
+    ts->d_zeros = ts->d_x + (size_t)(total + n_traj) * d;
     for (int j = 0; j < n_traj; ++j) {
         TrajDesc &td = ts->descs[j];
         std::memset(&td, 0, sizeof td);
         td.T = T[j];
-        td.x = ts->d_x + off * d;
+        const int64_t doff = off + j; // device row offset: j padding rows precede trajectory j
+        td.x = ts->d_x + doff * d;
         int nvalid = 0;
         for (int t = 0; t < T[j]; ++t) {
             bool valid = true;
             for (int k = 0; k < d; ++k) valid &= !std::isnan(x[(off + t) * d + k]);
-            for (int k = 0; k < d; ++k) xd[(off + t) * d + k] = valid ? x[(off + t) * d + k] : qnan;
+            for (int k = 0; k < d; ++k) xd[(doff + t) * d + k] = valid ? x[(off + t) * d + k] : qnan;
             nvalid += valid;
         }
         td.nvalid = nvalid;

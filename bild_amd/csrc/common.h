@@ -31,7 +31,7 @@ struct StateBlock {
 constexpr int table_stride(int NP) { return NP * NP + 2; }
 
 struct TrajDesc {
-    const double *x; // device, T x d; every coordinate of a missing frame is NaN
+    const double *x; // device, (T + 1) x d: one padding row; every coordinate of a missing frame is NaN
     int32_t T;
     int32_t dstar;           // number of distinct localization errors (pyx:145)
     double s2[kDMax];        // their squares, ascending
@@ -53,6 +53,7 @@ struct KParams {
     const int32_t *seg_start;
     const int32_t *seg_state;
     const int32_t *traj_id; // may be null
+    const double *zeros;    // a few zero doubles (stride-0 source for non-mean columns)
     double *out;            // ntasks partial results
 };
 

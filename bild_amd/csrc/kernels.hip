@@ -88,8 +88,8 @@ __device__ __forceinline__ void matvec_to_lds(XPtr X, const Cols<NP, CPL> &in, d
     }
 }
 
-template <int NP, int CPL, int G, int W, int MODE>
-__global__ void __launch_bounds__(64 * W) logl_kernel(const KParams p)
+template <int NP, int CPL, int G, int W, int OCC, int MODE>
+__global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
 {
     constexpr int kThreads = 64 * W;
     constexpr int kWaves = W;
@@ -143,7 +143,6 @@ __global__ void __launch_bounds__(64 * W) logl_kernel(const KParams p)
         const int T = td->T;
         const double s2 = td->s2[e];
         const int nd = td->ndims[e];
-        const double *__restrict__ xg = td->x;
 
         bool isM[CPL];
         int xoff[CPL];
@@ -154,6 +153,31 @@ __global__ void __launch_bounds__(64 * W) logl_kernel(const KParams p)
             xoff[q] = isM[q] ? td->dims[e][mi] : 0;
         }
 
+        // Trajectory stream.  The pointers come out of memory: tell the compiler they are global,
+        // or every load becomes a flat_load (which also ties up lgkmcnt).  Each own column walks
+        // its own coordinate with a running pointer; columns that are not mean columns read a
+        // zero word with stride 0, so that  e = w.col - x  is the innovation sign-flipped for a
+        // mean column and plain Cw_j for a covariance column -- one formula, no selects.  The
+        // device copy has one padding row per trajectory: fetching one frame ahead never leaves it.
+        typedef const __attribute__((address_space(1))) double *gptr_t;
+        gptr_t px[CPL];
+        int xstep[CPL];
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+            px[q] = isM[q] ? (gptr_t)td->x + xoff[q] : (gptr_t)p.zeros;
+            xstep[q] = isM[q] ? d : 0;
+        }
+        gptr_t pprobe = (gptr_t)td->x; // coordinate 0 is NaN <=> frame missing
+        auto fetch = [&](double (&xv)[CPL], double &probe) {
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+                xv[q] = *px[q];
+                px[q] += xstep[q];
+            }
+            probe = *pprobe;
+            pprobe += d;
+        };
+
         const int32_t *__restrict__ sst = p.seg_start + r * K1;
         const int32_t *__restrict__ ssv = p.seg_state + r * K1;
         int seg = 0;
@@ -161,21 +185,30 @@ __global__ void __launch_bounds__(64 * W) logl_kernel(const KParams p)
         int next_start = (K1 > 1) ? sst[1] : INT_MAX;
 
         // ---- per-state registers -------------------------------------------------
-        double wq[NP];   // measurement vector in the current basis
-        double lam[NP];  // modal: eigenvalues of B_s
-        double mu[CPL];  // modal: column factor (lam_c for covariance columns, 1 for mean columns)
-        double sgc[CPL]; // modal: process-noise variance of the own diagonal element
+        double wq[NP]; // measurement vector in the current basis
+        // modal predict  C'_ij <- lam_i lam_j C'_ij + sig_i delta_ij,  M'_i <- lam_i M'_i  as ONE
+        // fma per entry: L[q][i] = lam_i * (lam_c or 1), sgd[i] = sig_c on the own diagonal entry
+        // (row i == column c of column slot q = i % CPL) and 0 elsewhere.  Rebuilt at switches.
+        Cols<NP, CPL> L;
+        double sgd[NP];
         auto load_state = [&](int st) {
             const double *__restrict__ sb = p.states + (size_t)st * SB;
 #pragma unroll
             for (int i = 0; i < NP; ++i) wq[i] = sb[StateBlock::wq(NP) + i];
             if (MODE == kModal) {
-#pragma unroll
-                for (int i = 0; i < NP; ++i) lam[i] = sb[StateBlock::lam(NP) + i];
+                double mu[CPL], sgc[CPL];
 #pragma unroll
                 for (int q = 0; q < CPL; ++q) {
-                    mu[q] = isC[q] ? sb[StateBlock::lam(NP) + cidx[q]] : 1.0;
-                    sgc[q] = isC[q] ? sb[StateBlock::sig(NP) + cidx[q]] : 0.0;
+                    const int cc = isC[q] ? cidx[q] : 0;
+                    mu[q] = isC[q] ? sb[StateBlock::lam(NP) + cc] : (hasImg[q] ? 1.0 : 0.0);
+                    sgc[q] = isC[q] ? sb[StateBlock::sig(NP) + cc] : 0.0;
+                }
+#pragma unroll
+                for (int i = 0; i < NP; ++i) {
+                    const double li = sb[StateBlock::lam(NP) + i];
+#pragma unroll
+                    for (int q = 0; q < CPL; ++q) L.v[q][i] = li * mu[q];
+                    sgd[i] = (gl == i / CPL) ? sgc[i % CPL] : 0.0;
                 }
             }
         };
@@ -195,14 +228,15 @@ __global__ void __launch_bounds__(64 * W) logl_kernel(const KParams p)
             }
         }
 
-        double acc = 0.0; // sum over own mean columns of nu^2 / S
-        double P = 1.0;   // running product of S (mantissa), exponent in E
+        double accq[CPL]; // per own column: sum of e^2 / S (meaningful for mean columns)
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) accq[q] = 0.0;
+        double P = 1.0; // running product of S (mantissa), exponent in E
         int E = 0;
-        int nvalid = 0;
 
         // ---- Kalman update (pyx:19-90) ---------------------------------------------
         auto update = [&](const double (&xv)[CPL]) {
-            double dotv[CPL];
+            double ev[CPL];
 #pragma unroll
             for (int q = 0; q < CPL; ++q) {
                 double a0 = 0.0, a1 = 0.0;
@@ -211,11 +245,11 @@ __global__ void __launch_bounds__(64 * W) logl_kernel(const KParams p)
                     a0 = fma(wq[i], col.v[q][i], a0);
                     a1 = fma(wq[i + 1], col.v[q][i + 1], a1);
                 }
-                dotv[q] = a0 + a1;
+                ev[q] = (a0 + a1) - xv[q]; // covariance column: (C w)_c ; mean column: -(x - w.M)
             }
 #pragma unroll
             for (int q = 0; q < CPL; ++q)
-                if (isC[q]) scratch[cidx[q]] = dotv[q];
+                if (isC[q]) scratch[cidx[q]] = ev[q];
             wave_lds_fence();
             double cw[NP];
 #pragma unroll
@@ -232,26 +266,19 @@ __global__ void __launch_bounds__(64 * W) logl_kernel(const KParams p)
                 sb2 = fma(wq[i + 1], cw[i + 1], sb2);
             }
             const double Sv = sa + sb2;
-            const double Sinv = 1.0 / Sv;
+            // 1/S: hardware reciprocal seed + two Newton steps (full double precision for the
+            // normal, positive S a covariance produces; NaN/Inf/0 propagate as such)
+            double Sinv = __builtin_amdgcn_rcp(Sv);
+            Sinv = fma(fma(-Sv, Sinv, 1.0), Sinv, Sinv);
+            Sinv = fma(fma(-Sv, Sinv, 1.0), Sinv, Sinv);
 #pragma unroll
             for (int q = 0; q < CPL; ++q) {
-                const double nu = xv[q] - dotv[q];
-                const double coef = isC[q] ? dotv[q] * Sinv : (isM[q] ? -nu * Sinv : 0.0);
-                if (isM[q]) acc = fma(nu * nu, Sinv, acc);
+                const double coef = ev[q] * Sinv; // K_c * S for a covariance column, -nu/S for a mean column
+                accq[q] = fma(ev[q] * ev[q], Sinv, accq[q]);
 #pragma unroll
                 for (int i = 0; i < NP; ++i) col.v[q][i] = fma(-coef, cw[i], col.v[q][i]);
             }
-            int ex;
-            P = frexp(P * Sv, &ex);
-            E += ex;
-            ++nvalid;
-        };
-
-        auto load_x = [&](int t, double (&xv)[CPL]) -> double {
-            const double *__restrict__ row = xg + (size_t)t * d;
-#pragma unroll
-            for (int q = 0; q < CPL; ++q) xv[q] = row[xoff[q]];
-            return row[0];
+            P *= Sv;
         };
 
         // A <- X A for all columns, then C <- C X^T for the covariance part: two lane-local
@@ -289,17 +316,8 @@ __global__ void __launch_bounds__(64 * W) logl_kernel(const KParams p)
             wave_lds_fence();
         };
 
-        // ---- frame 0: update on the steady state, no predict (pyx:186-190) ----------
-        {
-            double xv[CPL];
-            const double probe = load_x(0, xv);
-            if (!isnan(probe)) update(xv);
-        }
-
-        for (int t = 1; t < T; ++t) {
-            double xv[CPL];
-            const double probe = load_x(t, xv);
-
+        // one frame t >= 1: state bookkeeping, predict (pyx:206-241), masked update (pyx:244-248)
+        auto frame = [&](int t, const double (&xv)[CPL], double probe) {
             if (t >= next_start) {
                 do {
                     ++seg;
@@ -307,23 +325,17 @@ __global__ void __launch_bounds__(64 * W) logl_kernel(const KParams p)
                 } while (t >= next_start);
                 const int sn = ssv[seg];
                 if (sn != s) {
-                    if (MODE == kModal) {
-                        sandwich(p.tab + (size_t)(sn * S + s) * MS, [] {});
-                    }
+                    if (MODE == kModal) sandwich(p.tab + (size_t)(sn * S + s) * MS, [] {});
                     s = sn;
                     load_state(s);
                 }
             }
-
-            // ---- predict (pyx:206-241) ---------------------------------------------
             if (MODE == kModal) {
 #pragma unroll
                 for (int q = 0; q < CPL; ++q)
 #pragma unroll
-                    for (int i = 0; i < NP; ++i) col.v[q][i] *= lam[i] * mu[q];
-#pragma unroll
-                for (int i = 0; i < NP; ++i)
-                    if (gl == i / CPL) col.v[i % CPL][i] += sgc[i % CPL];
+                    for (int i = 0; i < NP; ++i)
+                        col.v[q][i] = (q == i % CPL) ? fma(L.v[q][i], col.v[q][i], sgd[i]) : L.v[q][i] * col.v[q][i];
                 if (p.has_G) {
                     const double *__restrict__ gb = p.states + (size_t)s * SB + StateBlock::G(NP);
 #pragma unroll
@@ -359,11 +371,32 @@ __global__ void __launch_bounds__(64 * W) logl_kernel(const KParams p)
                         }
                     }
             }
-
             if (!isnan(probe)) update(xv);
+            if ((t & 3) == 0) { // keep the running product of S in range (wave-uniform condition)
+                int ex;
+                P = frexp(P, &ex);
+                E += ex;
+            }
+        };
+
+        // ---- frame 0: update on the steady state, no predict (pyx:186-190); frames are
+        // fetched one ahead of their use ----------------------------------------------------
+        double xc[CPL], xn[CPL], pc, pn;
+        fetch(xc, pc); // frame 0
+        fetch(xn, pn); // frame 1 (or the padding row)
+        if (!isnan(pc)) update(xc);
+        for (int t = 1; t < T; ++t) {
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) xc[q] = xn[q];
+            pc = pn;
+            fetch(xn, pn); // frame t + 1 (<= T: the padding row at most)
+            frame(t, xc, pc);
         }
 
         // ---- sum of the per-frame log-densities (pyx:88, 251-256) ---------------------
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) acc += isM[q] ? accq[q] : 0.0;
         scratch[gl] = acc;
         wave_lds_fence();
         if (gl == 0) {
@@ -371,7 +404,7 @@ __global__ void __launch_bounds__(64 * W) logl_kernel(const KParams p)
 #pragma unroll
             for (int g2 = 0; g2 < G; ++g2) tot += scratch[g2];
             const double logS = log(P) + (double)E * kLn2;
-            tot += (double)nd * (logS + (double)nvalid * kLog2Pi);
+            tot += (double)nd * (logS + (double)td->nvalid * kLog2Pi);
             p.out[task] = -0.5 * tot;
         }
         wave_lds_fence();
@@ -388,18 +421,18 @@ __global__ void reduce_partials_kernel(const double *__restrict__ partial, doubl
     out[r] = tot;
 }
 
-template <int NP, int CPL, int G, int W>
+template <int NP, int CPL, int G, int W, int OCC>
 int launch_geom(int mode, const KParams &p, int grid, size_t lds, hipStream_t st)
 {
     constexpr int kThreads = 64 * W;
     hipError_t err;
     if (mode == kModal) {
-        auto k = logl_kernel<NP, CPL, G, W, kModal>;
+        auto k = logl_kernel<NP, CPL, G, W, OCC, kModal>;
         err = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess) return (int)err;
         hipLaunchKernelGGL(k, dim3(grid), dim3(kThreads), lds, st, p);
     } else {
-        auto k = logl_kernel<NP, CPL, G, W, kDense>;
+        auto k = logl_kernel<NP, CPL, G, W, OCC, kDense>;
         err = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess) return (int)err;
         hipLaunchKernelGGL(k, dim3(grid), dim3(kThreads), lds, st, p);
@@ -407,21 +440,25 @@ int launch_geom(int mode, const KParams &p, int grid, size_t lds, hipStream_t st
     return (int)hipGetLastError();
 }
 
-// (rows, columns per lane, lanes per group, waves per workgroup); CPL * G >= NP + 3.
-// W is chosen so that W * (64/G) group images + the dense tables fit in 160 KiB of LDS.
+// (rows, columns per lane, lanes per group, waves per workgroup, min waves per SIMD);
+// CPL * G >= NP + 3.  W is chosen so that W * (64/G) group images + the dense tables fit in
+// 160 KiB of LDS; OCC bounds the register allocation (512 / OCC VGPRs per lane).
+#ifndef BILD_OCC10
+#define BILD_OCC10 2 // experiment knob (tools/ab.py): min waves per SIMD of the NP = 10 kernels
+#endif
 #define BILD_GEOMETRIES(X) \
-    X(4, 1, 8, 4)          \
-    X(8, 3, 4, 4)          \
-    X(10, 2, 8, 4)         \
-    X(12, 2, 8, 4)         \
-    X(16, 3, 8, 4)         \
-    X(20, 3, 8, 4)         \
-    X(24, 4, 8, 2)         \
-    X(28, 4, 8, 2)         \
-    X(32, 3, 16, 2)
+    X(4, 1, 8, 4, 2)       \
+    X(8, 3, 4, 4, 2)       \
+    X(10, 2, 8, 4, BILD_OCC10) \
+    X(12, 2, 8, 4, 2)      \
+    X(16, 3, 8, 4, 1)      \
+    X(20, 3, 8, 4, 1)      \
+    X(24, 4, 8, 2, 1)      \
+    X(28, 4, 8, 2, 1)      \
+    X(32, 3, 16, 2, 1)
 
 constexpr Geometry kGeoms[] = {
-#define X(NP, CPL, G, W) {NP, CPL, G, W},
+#define X(NP, CPL, G, W, OCC) {NP, CPL, G, W},
     BILD_GEOMETRIES(X)
 #undef X
 };
@@ -444,8 +481,8 @@ int launch_logl(const Geometry &g, int mode, const KParams &p, int grid, size_t 
 {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     switch (g.NP) {
-#define X(NP, CPL, G, W) \
-    case NP: return launch_geom<NP, CPL, G, W>(mode, p, grid, lds, st);
+#define X(NP, CPL, G, W, OCC) \
+    case NP: return launch_geom<NP, CPL, G, W, OCC>(mode, p, grid, lds, st);
         BILD_GEOMETRIES(X)
 #undef X
     default: return -1;
