@@ -106,7 +106,7 @@ struct bild_model {
     std::string modal_why;
     Mat lam, sigd, Q, wq, R, C0q, M0q, Gq; // S*n, S*n, S*n*n, S*n, S*S*n*n, S*n*n, S*n*d, S*n*d
     // packed for the kernels
-    Geometry geom{0, 0, 0, 0};
+    int NP = 0; // padded row count; the launch geometry is chosen per batch (geometry_for)
     Mat blob_states[2], blob_tab[2];
     // device residency
     mutable std::mutex mu;
@@ -373,9 +373,10 @@ int analyse(bild_model &m)
     }
 
     // ---- pack --------------------------------------------------------------------------
-    if (!geometry_for(n, &m.geom))
+    m.NP = padded_rows(n);
+    if (!m.NP)
         return fail(BILD_ERR_UNSUPPORTED, "chain of %d effective modes exceeds the compiled kernels (max %d)", n, kMaxNP);
-    const int NP = m.geom.NP;
+    const int NP = m.NP;
     const int SB = StateBlock::size(NP);
     const int MS = table_stride(NP);
     for (int mode = 0; mode < 2; ++mode) {
@@ -421,12 +422,12 @@ int analyse(bild_model &m)
     return BILD_OK;
 }
 
-size_t lds_bytes(const bild_model &m, int mode)
+size_t lds_bytes(const bild_model &m, const Geometry &geom, int mode)
 {
     // dense: propagator tables + per-group product images; modal: product images only (the
     // basis-change matrices are read through L2, they are touched only at state switches)
-    const size_t groups = (size_t)m.geom.W * (64 / m.geom.G);
-    const size_t image = (size_t)group_image_doubles(m.geom.NP);
+    const size_t groups = (size_t)geom.W * (64 / geom.G);
+    const size_t image = (size_t)group_image_doubles(geom.NP);
     return ((mode == kDense ? m.blob_tab[mode].size() : 0) + groups * image) * sizeof(double);
 }
 
@@ -467,7 +468,9 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
     int mode;
     int rc = pick_mode(m, flags, &mode);
     if (rc) return rc;
-    const size_t lds = lds_bytes(m, mode);
+    Geometry geom;
+    if (!geometry_for(m.NP, n * ts.dstar_max, &geom)) return fail(BILD_ERR_UNSUPPORTED, "no kernel for %d rows", m.NP);
+    const size_t lds = lds_bytes(m, geom, mode);
     if (lds > 160 * 1024)
         return fail(BILD_ERR_UNSUPPORTED, "model tables need %zu bytes of LDS (> 160 KiB): too many states for chain length %d", lds, m.n);
 
@@ -495,8 +498,7 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
     }
     p.out = target;
 
-    const int gpw = 64 / m.geom.G;
-    const int64_t tasks_per_block = (int64_t)m.geom.W * gpw;
+    const int64_t tasks_per_block = (int64_t)geom.W * geom.tasks_per_wave();
     int64_t blocks = (p.ntasks + tasks_per_block - 1) / tasks_per_block;
     const int grid = (int)std::min<int64_t>(std::max<int64_t>(blocks, 1), 256 * 16);
 
@@ -511,13 +513,13 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, st));
     }
-    int lrc = launch_logl(m.geom, mode, p, grid, lds, (void *)st);
+    int lrc = launch_logl(geom, mode, p, grid, lds, (void *)st);
     if (lrc != 0) return fail(BILD_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
     if (timing) {
         HIP_TRY(hipEventRecord(e1, st));
         std::lock_guard<std::mutex> lk(g_time_mu);
         g_time_events.emplace_back(e0, e1);
-        g_time_name = kernel_name(m.geom, mode);
+        g_time_name = kernel_name(geom, mode);
     }
     if (ts.dstar_max > 1) {
         lrc = launch_reduce_partials(target, d_out, n, ts.dstar_max, (void *)st);
@@ -604,7 +606,7 @@ int bild_model_query(const bild_model *m, int what, int64_t *value)
     case BILD_Q_D: *value = m->d; break;
     case BILD_Q_S: *value = m->S; break;
     case BILD_Q_MODAL_OK: *value = m->modal_ok; break;
-    case BILD_Q_NP: *value = m->geom.NP; break;
+    case BILD_Q_NP: *value = m->NP; break;
     case BILD_Q_NEFF: *value = m->n; break;
     case BILD_Q_HAS_G: *value = m->has_G; break;
     default: return fail(BILD_ERR_INVALID, "unknown query %d", what);

@@ -61,6 +61,9 @@ struct KParams {
 struct Geometry {
     int NP, CPL, G; // padded rows, columns per lane, lanes per group
     int W;          // wavefronts per workgroup
+    int OCC;        // wavefronts per SIMD the register allocation is bounded for
+    int id;         // index into the compiled-kernel table
+    int tasks_per_wave() const { return 64 / G; }
 };
 
 // doubles of LDS one group needs: image of X*[C|M], NP+kDMax columns of NP rows
@@ -69,7 +72,11 @@ constexpr int group_image_doubles(int NP) { return (NP + kDMax) * NP; }
 // host-callable launchers implemented in kernels.hip
 int launch_logl(const Geometry &g, int mode, const KParams &p, int grid, size_t lds_bytes, void *stream);
 int launch_reduce_partials(const double *partial, double *out, int64_t n, int dstar_max, void *stream);
-bool geometry_for(int n_rows, Geometry *g);
+// smallest compiled row count >= n_rows, or 0
+int padded_rows(int n_rows);
+// launch geometry for `ntasks` recursions of a chain padded to NP rows (several are compiled per NP:
+// few tasks per wave for small batches, many for throughput); env BILD_GEOM=<id> overrides.
+bool geometry_for(int NP, int64_t ntasks, Geometry *g);
 const char *kernel_name(const Geometry &g, int mode);
 
 } // namespace bild

@@ -34,6 +34,7 @@
 #include <hip/hip_runtime.h>
 #include <limits.h>
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -88,7 +89,7 @@ __device__ __forceinline__ void matvec_to_lds(XPtr X, const Cols<NP, CPL> &in, d
     }
 }
 
-template <int NP, int CPL, int G, int W, int OCC, int MODE>
+template <int NP, int CPL, int G, int W, int OCC, int MODE, bool HASG>
 __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
 {
     constexpr int kThreads = 64 * W;
@@ -98,7 +99,6 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
     constexpr int SB = StateBlock::size(NP);
     static_assert(NP % 2 == 0, "rows are read in pairs");
     static_assert(CPL * G >= NP + kDMax, "not enough columns for [C | M]");
-    static_assert(64 % G == 0, "groups must tile the wavefront");
 
     extern __shared__ __align__(16) double smem[];
 
@@ -114,6 +114,7 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
     }
     // per-group scratch: image of X*A, NP + kDMax columns of NP doubles; its first NP doubles
     // double as the all-gather buffer of the update
+    if (grp >= GPW) return; // lanes beyond the last whole group (64 % G != 0) idle
     const int lds_tab = (MODE == kDense) ? p.tab_doubles : 0;
     double *const scratch = smem + lds_tab + (size_t)(wv * GPW + grp) * group_image_doubles(NP);
 
@@ -247,9 +248,10 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
                 }
                 ev[q] = (a0 + a1) - xv[q]; // covariance column: (C w)_c ; mean column: -(x - w.M)
             }
+            // every lane publishes (no exec masking): mean / spare columns land behind the NP
+            // gathered entries (cidx < CPL*G <= group image size)
 #pragma unroll
-            for (int q = 0; q < CPL; ++q)
-                if (isC[q]) scratch[cidx[q]] = ev[q];
+            for (int q = 0; q < CPL; ++q) scratch[cidx[q]] = ev[q];
             wave_lds_fence();
             double cw[NP];
 #pragma unroll
@@ -278,7 +280,9 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
 #pragma unroll
                 for (int i = 0; i < NP; ++i) col.v[q][i] = fma(-coef, cw[i], col.v[q][i]);
             }
-            P *= Sv;
+            int ex;
+            P = frexp(P * Sv, &ex);
+            E += ex;
         };
 
         // A <- X A for all columns, then C <- C X^T for the covariance part: two lane-local
@@ -336,7 +340,7 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
 #pragma unroll
                     for (int i = 0; i < NP; ++i)
                         col.v[q][i] = (q == i % CPL) ? fma(L.v[q][i], col.v[q][i], sgd[i]) : L.v[q][i] * col.v[q][i];
-                if (p.has_G) {
+                if (HASG) {
                     const double *__restrict__ gb = p.states + (size_t)s * SB + StateBlock::G(NP);
 #pragma unroll
                     for (int q = 0; q < CPL; ++q)
@@ -347,7 +351,7 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
                 }
             } else {
                 const double *__restrict__ sb = p.states + (size_t)s * SB;
-                const int has_G = p.has_G;
+                constexpr bool has_G = HASG;
                 sandwich(const_cast<const double *>(smem) + (size_t)s * MS, [&] {
                     if (has_G) {
 #pragma unroll
@@ -372,11 +376,6 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
                     }
             }
             if (!isnan(probe)) update(xv);
-            if ((t & 3) == 0) { // keep the running product of S in range (wave-uniform condition)
-                int ex;
-                P = frexp(P, &ex);
-                E += ex;
-            }
         };
 
         // ---- frame 0: update on the steady state, no predict (pyx:186-190); frames are
@@ -426,53 +425,73 @@ int launch_geom(int mode, const KParams &p, int grid, size_t lds, hipStream_t st
 {
     constexpr int kThreads = 64 * W;
     hipError_t err;
-    if (mode == kModal) {
-        auto k = logl_kernel<NP, CPL, G, W, OCC, kModal>;
+    auto go = [&](auto k) -> int {
         err = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess) return (int)err;
         hipLaunchKernelGGL(k, dim3(grid), dim3(kThreads), lds, st, p);
-    } else {
-        auto k = logl_kernel<NP, CPL, G, W, OCC, kDense>;
-        err = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (err != hipSuccess) return (int)err;
-        hipLaunchKernelGGL(k, dim3(grid), dim3(kThreads), lds, st, p);
-    }
-    return (int)hipGetLastError();
+        return (int)hipGetLastError();
+    };
+    // G != 0 (an external force on the chain) never occurs through the reference's entry points
+    // (rouse.Model is built with F = 0, models.py:246): keep it out of the common kernels
+    if (mode == kModal) return p.has_G ? go(logl_kernel<NP, CPL, G, W, OCC, kModal, true>) : go(logl_kernel<NP, CPL, G, W, OCC, kModal, false>);
+    return p.has_G ? go(logl_kernel<NP, CPL, G, W, OCC, kDense, true>) : go(logl_kernel<NP, CPL, G, W, OCC, kDense, false>);
 }
 
-// (rows, columns per lane, lanes per group, waves per workgroup, min waves per SIMD);
+// (id, rows, columns per lane, lanes per group, waves per workgroup, min waves per SIMD);
 // CPL * G >= NP + 3.  W is chosen so that W * (64/G) group images + the dense tables fit in
-// 160 KiB of LDS; OCC bounds the register allocation (512 / OCC VGPRs per lane).
-#ifndef BILD_OCC10
-#define BILD_OCC10 2 // experiment knob (tools/ab.py): min waves per SIMD of the NP = 10 kernels
-#endif
-#define BILD_GEOMETRIES(X) \
-    X(4, 1, 8, 4, 2)       \
-    X(8, 3, 4, 4, 2)       \
-    X(10, 2, 8, 4, BILD_OCC10) \
-    X(12, 2, 8, 4, 2)      \
-    X(16, 3, 8, 4, 1)      \
-    X(20, 3, 8, 4, 1)      \
-    X(24, 4, 8, 2, 1)      \
-    X(28, 4, 8, 2, 1)      \
-    X(32, 3, 16, 2, 1)
+// 160 KiB of LDS; OCC bounds the register allocation (512 / OCC VGPRs per lane).  The table
+// may hold several geometries per NP (geometry_for picks by batch size); measured on MI355X
+// for NP = 10, (CPL, G) = (3, 5) and (5, 3) -- fewer lanes per task, fewer instructions per
+// task -- lose to (2, 8) at every batch size because they run at one wave per SIMD with a
+// longer dependent chain per frame (profiles/r01_geometry_sweep.txt), so one entry per NP.
+#define BILD_GEOMETRIES(X)  \
+    X(0, 4, 1, 8, 4, 2)     \
+    X(1, 8, 3, 4, 4, 2)     \
+    X(2, 10, 2, 8, 4, 2)    \
+    X(3, 12, 2, 8, 4, 2)    \
+    X(4, 16, 3, 8, 4, 1)    \
+    X(5, 20, 3, 8, 4, 1)    \
+    X(6, 24, 4, 8, 2, 1)    \
+    X(7, 28, 4, 8, 2, 1)    \
+    X(8, 32, 3, 16, 2, 1)
 
 constexpr Geometry kGeoms[] = {
-#define X(NP, CPL, G, W, OCC) {NP, CPL, G, W},
+#define X(ID, NP, CPL, G, W, OCC) {NP, CPL, G, W, OCC, ID},
     BILD_GEOMETRIES(X)
 #undef X
 };
+constexpr int kNumGeoms = sizeof(kGeoms) / sizeof(kGeoms[0]);
 
 } // namespace
 
-bool geometry_for(int n_rows, Geometry *g)
+int padded_rows(int n_rows)
 {
     for (const Geometry &c : kGeoms)
-        if (c.NP >= n_rows) {
-            *g = c;
+        if (c.NP >= n_rows) return c.NP;
+    return 0;
+}
+
+bool geometry_for(int NP, int64_t ntasks, Geometry *g)
+{
+    if (const char *ov = getenv("BILD_GEOM")) {
+        const int id = atoi(ov);
+        if (id >= 0 && id < kNumGeoms && kGeoms[id].NP == NP) {
+            *g = kGeoms[id];
             return true;
         }
-    return false;
+    }
+    // candidates are listed by increasing tasks per wave: take the first one that still puts at
+    // most one wave on every SIMD (256 CUs x 4), else the densest
+    const Geometry *best = nullptr;
+    for (const Geometry &c : kGeoms) {
+        if (c.NP != NP) continue;
+        best = &c;
+        const int64_t waves = (ntasks + c.tasks_per_wave() - 1) / c.tasks_per_wave();
+        if (waves <= 1024) break;
+    }
+    if (!best) return false;
+    *g = *best;
+    return true;
 }
 
 const char *kernel_name(const Geometry &, int mode) { return mode == kModal ? "logl_kernel<modal>" : "logl_kernel<dense>"; }
@@ -480,9 +499,9 @@ const char *kernel_name(const Geometry &, int mode) { return mode == kModal ? "l
 int launch_logl(const Geometry &g, int mode, const KParams &p, int grid, size_t lds, void *stream)
 {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    switch (g.NP) {
-#define X(NP, CPL, G, W, OCC) \
-    case NP: return launch_geom<NP, CPL, G, W, OCC>(mode, p, grid, lds, st);
+    switch (g.id) {
+#define X(ID, NP, CPL, G, W, OCC) \
+    case ID: return launch_geom<NP, CPL, G, W, OCC>(mode, p, grid, lds, st);
         BILD_GEOMETRIES(X)
 #undef X
     default: return -1;

@@ -141,6 +141,20 @@ def main():
     ss, th = H.candidate_profiles(rng, 3, 4, 2)
     save('s2_d3_T1000', model, traj, [truth] + list(H.expand(ss, th, 1000)), "headline shape N=20 d=3 d*=1 T=1000 2-state")
 
+    # 9. external force on the chain: G != 0 and a non-zero steady-state mean M0 (never produced by the
+    #    reference's own constructor, which builds rouse.Model with F = 0, but the kernels accept it)
+    rng = np.random.default_rng(12)
+    model = H.DuckModel(N=20, D=1, k=5, d=3, localization_error=[0.1, 0.1, 0.2])
+    for mi, mod in enumerate(model.models):
+        mod.F[0, :] = [0.5, -0.25, 0.1 * (mi + 1)]
+        mod.F[-1, :] = [-0.5, 0.25, -0.1 * (mi + 1)]
+        mod.F[7, 1] = 0.3
+        mod.update_dynamics()
+    truth = H.random_profile(rng, 120, 2, 30)
+    traj = H.synth_trajectory(model, truth, [0.1, 0.1, 0.2], rng, missing=H.missing_mask(rng, 120, 'iid'))
+    ss, th = H.candidate_profiles(rng, 5, 3, 2)
+    save('force_G_T120', model, traj, [truth] + list(H.expand(ss, th, 120)), "non-zero G and M0 (external force), d*=2")
+
 
 if __name__ == '__main__':
     main()

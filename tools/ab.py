@@ -40,10 +40,16 @@ def run(argv):
         samples = argv[argv.index('--samples') + 1]
     if '--extra' in argv:
         extra = argv[argv.index('--extra') + 1].split()
+    geoms = ['']
+    if '--geoms' in argv:
+        geoms = argv[argv.index('--geoms') + 1].split(',')
     variants = sorted(f for f in os.listdir(VDIR) if f.endswith('.so'))
+    variants = [(v, g) for v in variants for g in geoms]
     for ns in samples.split(','):
-        for v in variants:
+        for v, g in variants:
             env = dict(os.environ, BILD_AMD_LIB=os.path.join(VDIR, v))
+            if g != '':
+                env['BILD_GEOM'] = g
             cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '30', '--warmup', '3', '--no-cpu-baseline',
                    '--no-dense', '--samples', ns] + extra
             r = subprocess.run(cmd, env=env, capture_output=True, text=True)
@@ -52,7 +58,7 @@ def run(argv):
                 print(f"{v:40s} n={ns:>7s} FAILED\n{r.stderr[-2000:]}")
                 continue
             j = json.loads(line[-1])
-            print(f"{v[12:-3]:28s} n={ns:>7s} value={j['value'] / 1e6:8.3f} M/s  kernel={j['roofline']['kernel_ms'] * 1e3:9.1f} us"
+            print(f"{v[12:-3] + ('/g' + g if g else ''):28s} n={ns:>7s} value={j['value'] / 1e6:8.3f} M/s  kernel={j['roofline']['kernel_ms'] * 1e3:9.1f} us"
                   f"  exec_frac={j['roofline']['executed_frac']:.3f}", flush=True)
 
 
