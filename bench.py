@@ -178,6 +178,16 @@ def main():
     dt, kernel_ms, kname = timed(args.path, args.steps, args.warmup)
     value = world * n * args.steps / dt
 
+    # HBM bytes per launch measured with rocprofv3 PMC passes (profiles/*_hbm_traffic.json), quoted only
+    # when the committed measurement is for this very workload
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')) as f:
+            tj = json.load(f)
+        if tj['workload'] == {'samples': n, 'T': T, 'k': k, 'path': args.path} and args.states == 2:
+            traffic = tj['traffic_bytes_raw']
+    except Exception:
+        pass
     can, exe = _lib.flop_count(h, ts, n, path=args.path)
     ksec = kernel_ms * 1e-3
     roofline = {
@@ -186,7 +196,8 @@ def main():
         'kernel': kname,
         'achieved': can / ksec / 1e12, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
         'frac': can / ksec / 1e12 / FP64_PEAK_TFLOPS,
-        'traffic': None,
+        'traffic': traffic,
+        'traffic_unit': 'bytes per launch (FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC, profiles/r01_hbm_traffic.json)',
         'flops_basis': 'canonical F of SURVEY 8a (dense recursion on all N monomers) x evaluations per launch',
         'flop_per_eval_canonical': can / n,
         'flop_per_eval_executed': exe / n,

@@ -445,11 +445,11 @@ int launch_geom(int mode, const KParams &p, int grid, size_t lds, hipStream_t st
 // task -- lose to (2, 8) at every batch size because they run at one wave per SIMD with a
 // longer dependent chain per frame (profiles/r01_geometry_sweep.txt), so one entry per NP.
 #define BILD_GEOMETRIES(X)  \
-    X(0, 4, 1, 8, 4, 2)     \
+    X(0, 4, 2, 4, 4, 2)     \
     X(1, 8, 3, 4, 4, 2)     \
-    X(2, 10, 2, 8, 4, 2)    \
+    X(2, 10, 2, 7, 4, 2)    \
     X(3, 12, 2, 8, 4, 2)    \
-    X(4, 16, 3, 8, 4, 1)    \
+    X(4, 16, 3, 7, 4, 1)    \
     X(5, 20, 3, 8, 4, 1)    \
     X(6, 24, 4, 8, 2, 1)    \
     X(7, 28, 4, 8, 2, 1)    \
