@@ -11,8 +11,8 @@ both evaluated by hand-written HIP kernels for gfx950 through the C ABI declared
 ``include/bild_amd.h`` (``bild_amd/libbild_amd.so``).  There is no CPU fallback.
 """
 from . import rouse, profiles, util, trajectory, models, amis  # noqa: F401
-from .models import MultiStateModel, MultiStateRouse  # noqa: F401
-from .amis import FixedkSampler  # noqa: F401
+from .models import MultiStateModel, MultiStateRouse, FactorizedModel  # noqa: F401
+from .amis import FixedkSampler, Dirichlet, CFC  # noqa: F401
 from .profiles import Loopingprofile  # noqa: F401
 from .trajectory import Trajectory  # noqa: F401
 

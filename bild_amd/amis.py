@@ -1,23 +1,261 @@
 """
-The AMIS batch boundary: `FixedkSampler.logL(ss, thetas)`.
+AMIS posterior sampling at a fixed number of switches k.
 
-Counterpart of reference bild/amis.py:623-739 restricted to what the hot path needs: the
-constructor's data members, ``st2profile`` and the batch likelihood.  Where the reference
-loops over the N samples of a step in Python and calls the model once per sample
-(bild/amis.py:735-739), this class hands the whole batch to the model in one call when the
-model offers ``logL_st_batch`` (the GPU-backed `MultiStateRouse` does), and otherwise
-behaves exactly like the reference.
+Counterpart of reference bild/amis.py: the proposal families
+(`Dirichlet` over switch intervals, `CFC` over state traces) and the `FixedkSampler` whose
+``logL(ss, thetas)`` is the batch boundary of the GPU likelihood (bild/amis.py:717-739).
+
+Everything here except ``FixedkSampler.logL`` is cheap host-side O(N k) bookkeeping and stays
+in NumPy.  Behaviour follows the reference function by function (citations in the
+docstrings); the random streams are consumed in the same order (``scipy.stats.dirichlet.rvs``,
+``np.random.choice``, ``np.random.rand``), so that with the same ``np.random.seed`` and the
+same likelihood values a sampler of this module and a reference sampler walk through
+identical proposals, weights and evidences (tests/test_amis_parity.py).
+
+Profiles are parametrised as ``(s, theta)``: ``s`` (k+1,) interval lengths on the unit
+simplex, ``theta`` (k+1,) the state of each interval; neighbouring states obey the model's
+``transitions`` matrix.
 """
+import itertools
+import math
+
 import numpy as np
+from scipy import stats
+from scipy.special import gammaln, logsumexp, xlogy
 
 from .profiles import Loopingprofile, switch_indices
 
 
+# ----------------------------------------------------------------------------------------
+# helpers
+# ----------------------------------------------------------------------------------------
+def _masked_logsumexp(logx, mask, axis):
+    """ log(sum(exp(logx) * mask)) without warnings for empty selections (-> -inf) """
+    with np.errstate(under='ignore', divide='ignore'):
+        return logsumexp(logx, b=mask, axis=axis)
+
+
+def _int_matrix_power(T, p):
+    """ exact integer matrix power (python ints: path counts overflow int64 for long traces) """
+    n = len(T)
+    result = [[int(i == j) for j in range(n)] for i in range(n)]
+    base = [[int(v) for v in row] for row in T]
+
+    def mul(A, B):
+        return [[sum(A[i][l] * B[l][j] for l in range(n)) for j in range(n)] for i in range(n)]
+    while p > 0:
+        if p & 1:
+            result = mul(result, base)
+        base = mul(base, base)
+        p >>= 1
+    return result
+
+
+def _safe_log(x):
+    return math.log(x) if x > 0 else -np.inf
+
+
+# ----------------------------------------------------------------------------------------
+# proposal over switch intervals
+# ----------------------------------------------------------------------------------------
+class Dirichlet:
+    """ Dirichlet distribution with a weighted method-of-moments fit (bild/amis.py:59-151) """
+
+    def sample(self, a, N=1):
+        """ (N, k+1) draws (bild/amis.py:66-81) """
+        return stats.dirichlet(a).rvs(N)
+
+    def logpdf(self, a, ss):
+        """
+        log density at the rows of ``ss`` (bild/amis.py:83-108).
+
+        A sample with ``s_i == 0`` where ``a_i < 1`` sits on a pole of the density: ``+inf``
+        (pinned by reference tests/test_amis.py:51-54).
+        """
+        a = np.asarray(a, dtype=np.float64)
+        ss = np.atleast_2d(np.asarray(ss, dtype=np.float64))
+        log_norm = gammaln(np.sum(a)) - np.sum(gammaln(a))
+        with np.errstate(divide='ignore', invalid='ignore'):
+            out = log_norm + np.sum(xlogy(a - 1., ss), axis=1)
+        pole = np.any((ss == 0) & (a[None, :] < 1), axis=1)
+        out[pole] = np.inf
+        return out
+
+    def estimate(self, ss, log_weights):
+        """
+        Weighted method of moments (bild/amis.py:110-151): mean m, variance v per component,
+        total concentration ``A = mean(m (1-m) / v) - 1``, estimate ``A m``.
+        """
+        ss = np.asarray(ss, dtype=np.float64)
+        with np.errstate(under='ignore'):
+            w = np.exp(log_weights - np.max(log_weights))
+            w = w / np.sum(w)
+            m = w @ ss
+            v = w @ np.square(ss - m[None, :])
+        if np.any(v == 0):
+            total = 1e10  # degenerate sample: very concentrated but finite, the brake takes over
+        else:
+            total = np.mean(m * (1 - m) / v) - 1
+        return total * m
+
+
+# ----------------------------------------------------------------------------------------
+# proposal over state traces
+# ----------------------------------------------------------------------------------------
+class CFC:
+    """
+    Conflict Free Categorical (bild/amis.py:153-536): a distribution over state traces
+    ``theta`` (k+1 integers in [0, n)) whose consecutive entries must be allowed by
+    ``transitions``.  Parametrised by log-weights ``logp`` (n, k+1); sampling is causal: slot
+    ``i`` is drawn from ``p[:, i]`` restricted to the successors of ``theta[i-1]``.
+    """
+
+    def __init__(self, transitions):
+        self.transitions = np.array(transitions, dtype=bool, copy=True)
+        self.MOM_maxiter = 1000
+        self.MOM_precision = 1e-2
+
+    @property
+    def n(self):
+        return self.transitions.shape[0]
+
+    # -- sampling / evaluation ---------------------------------------------------------
+    def sample(self, logp, N=1):
+        """ (N, k+1) traces (bild/amis.py:223-256); same use of the global NumPy stream """
+        k1 = logp.shape[1]
+        assert k1 >= 1
+        with np.errstate(under='ignore'):
+            p = np.exp(logp - logsumexp(logp, axis=0))
+        thetas = np.empty((N, k1), dtype=int)
+        thetas[:, 0] = np.random.choice(self.n, size=N, p=p[:, 0])
+        for i in range(1, k1):
+            allowed = p[None, :, i] * self.transitions[thetas[:, i - 1]]  # (N, n)
+            cdf = np.cumsum(allowed, axis=1)
+            cdf /= cdf[:, [-1]]
+            thetas[:, i] = np.argmax(cdf > np.random.rand(N, 1), axis=1)  # first crossing
+        return thetas
+
+    def logpmf(self, logp, thetas):
+        """ log probability of each trace (bild/amis.py:258-282) """
+        thetas = np.asarray(thetas)
+        N, k1 = thetas.shape
+        picked = logp[thetas, np.arange(k1)[None, :]]                      # (N, k+1)
+        #  normaliser of slot i >= 1: weights of the successors of theta[i-1]
+        log_norm = _masked_logsumexp(logp.T[None, 1:, :], self.transitions[thetas[:, :-1]], axis=-1)  # (N, k)
+        with np.errstate(under='ignore'):
+            log_norm0 = logsumexp(logp[:, 0])
+        return np.sum(picked, axis=1) - np.sum(log_norm, axis=1) - log_norm0
+
+    # -- estimation -------------------------------------------------------------------
+    def estimate(self, thetas, log_weights):
+        """ weighted marginals per slot -> weight parameters (bild/amis.py:284-307) """
+        thetas = np.asarray(thetas)
+        hit = thetas[None, :, :] == np.arange(self.n)[:, None, None]       # (n, N, k+1)
+        log_marginals = _masked_logsumexp(np.asarray(log_weights)[None, :, None], hit, axis=1)
+        with np.errstate(under='ignore'):
+            log_marginals = log_marginals - logsumexp(log_marginals, axis=0, keepdims=True)
+        return self.logp_from_marginals(log_marginals)
+
+    def logp_from_marginals(self, log_marginals):
+        """ slot-by-slot inversion marginals -> weights (bild/amis.py:309-337) """
+        k1 = log_marginals.shape[1]
+        assert k1 >= 1
+        logp = np.empty(log_marginals.shape, dtype=float)
+        logp[:, 0] = log_marginals[:, 0]
+        for i in range(1, k1):
+            logp[:, i] = self.solve_marginals_single(log_marginals[:, i], log_marginals[:, i - 1])
+        return logp
+
+    def solve_marginals_single(self, logf, logg):
+        """
+        Fixed-point iteration  p_n = f_n / sum_{m -> n} g_m / (sum_{m -> j} p_j)
+        (bild/amis.py:339-399).  Stops when successive iterates differ by less than
+        ``MOM_precision`` in log space; ``RuntimeError`` after ``MOM_maxiter`` iterations.
+        """
+        logf = np.asarray(logf, dtype=float)
+        logg = np.asarray(logg, dtype=float)
+        # delta-like marginals need no iteration
+        if np.any(logf == 0):
+            return logf.copy()
+        if np.any(logg == 0):
+            assert np.all(logf[logg == 0] == -np.inf)
+            return logf.copy()
+
+        f_zero = logf == -np.inf
+        g_zero = logg == -np.inf
+        cur = logf
+        for _ in range(self.MOM_maxiter):
+            with np.errstate(under='ignore', invalid='ignore'):
+                out_norm = _masked_logsumexp(cur[None, :], self.transitions, axis=1)   # successors of m
+                out_norm[g_zero] = 0                                                    # avoid -inf + inf
+                flow = logg - out_norm
+                inflow = _masked_logsumexp(flow[:, None], self.transitions, axis=0)    # predecessors of n
+                inflow[f_zero] = 0
+                new = logf - inflow
+                new = new - logsumexp(new)
+            if np.max(np.abs(new[~f_zero] - cur[~f_zero])) < self.MOM_precision:
+                return new
+            cur = new
+        raise RuntimeError("Iteration did not converge")
+
+    # -- the uniform distribution over traces -----------------------------------------
+    def _path_counts(self, k):
+        """ powers T^0 .. T^k of the transition matrix with exact integers """
+        T = self.transitions.astype(int).tolist()
+        return [_int_matrix_power(T, i) for i in range(k + 1)]
+
+    def uniform_marginals(self, k):
+        """
+        Slot marginals of the uniform distribution over valid traces (bild/amis.py:401-453):
+        (#paths of length i ending in state) x (#paths of length k-i starting there).
+        """
+        n = self.n
+        pw = self._path_counts(k)
+        out = np.empty((n, k + 1), dtype=float)
+        for i in range(k + 1):
+            into = [sum(pw[i][a][s] for a in range(n)) for s in range(n)]          # column sums
+            outof = [sum(pw[k - i][s][b] for b in range(n)) for s in range(n)]     # row sums
+            counts = [into[s] * outof[s] for s in range(n)]
+            total = sum(counts)
+            out[:, i] = [_safe_log(c) - _safe_log(total) for c in counts]
+        return out
+
+    def logp_uniform(self, k):
+        """ weight parameters of the uniform distribution (bild/amis.py:455-476) """
+        return self.logp_from_marginals(self.uniform_marginals(k))
+
+    def N_total(self, k, log=False):
+        """ number of valid traces with k switches (bild/amis.py:478-497) """
+        N = sum(sum(row) for row in _int_matrix_power(self.transitions.astype(int).tolist(), k))
+        return math.log(N) if log else N
+
+    def full_sample(self, k, Nmax=1000):
+        """
+        All valid traces with k switches, lexicographically by depth-first expansion
+        (bild/amis.py:499-536); ``ValueError`` if there are more than ``Nmax``.
+        """
+        N = self.N_total(k)
+        if N > Nmax:
+            raise ValueError(f"Full sample would be {N} > Nmax = {Nmax} traces")
+        succ = [np.nonzero(row)[0].tolist() for row in self.transitions]
+        traces = [[s] for s in range(self.n)]
+        for _ in range(k):
+            traces = [tr + [nxt] for tr in traces for nxt in succ[tr[-1]]]
+        return np.array(traces, dtype=int).reshape(len(traces), k + 1)
+
+
+# ----------------------------------------------------------------------------------------
+# the sampler
+# ----------------------------------------------------------------------------------------
 class FixedkSampler:
     """
-    Holds one (trajectory, model, k) problem; evaluates batches of candidate profiles.
+    AMIS (Cornuet et al. 2012) for a fixed number of switches ``k``; one `step` draws ``N``
+    profiles from the current proposal, evaluates them, re-weights all samples drawn so far
+    against the mixture of all proposals used, and refits the proposal.
 
-    Parameters follow reference bild/amis.py:623-629.
+    Constructor, attributes and methods follow reference bild/amis.py:540-972.  The likelihood
+    of a batch is obtained with ONE call when the model offers ``logL_st_batch`` (the GPU
+    model does), else per sample as in the reference.
     """
 
     class ExhaustionImpractical(ValueError):
@@ -38,29 +276,48 @@ class FixedkSampler:
         self.exhausted = False
         self.traj = traj
         self.model = model
-        self.samples = []
-        self.evidences = []
 
+        if self.k >= len(self.traj):
+            # more switches than frames: unidentifiable by construction (bild/amis.py:641-648)
+            self.evidences = [(-np.inf, 1e-10, np.inf)]
+            self.exhausted = True
+            return
+
+        self.dirichlet = Dirichlet()
+        self.cfc = CFC(model.transitions)
+        self.parameters = [(np.ones(self.k + 1), self.cfc.logp_uniform(self.k))]
+        # uniform prior over profiles: k! / N_total (bild/amis.py:654-659)
+        self.logprior = float(np.sum(np.log(np.arange(self.k) + 1))) - self.cfc.N_total(self.k, log=True)
+
+        self.samples = []    # dicts: 'ss', 'thetas', 'logLs' [, 'logδs', 'log_weights', 'cur_log_proposal']
+        self.evidences = []  # (logev, dlogev, KL) per step
+
+        try:
+            self.fix_exhaustive()
+        except FixedkSampler.ExhaustionImpractical:
+            pass
+
+    # -- profile encoding -----------------------------------------------------------------
     def st2profile(self, s, theta):
-        """
-        (s, theta) -> Loopingprofile, reference bild/amis.py:670-695.
-
-        s : (k+1,) float, on the unit simplex;  theta : (k+1,) int
-        """
+        """ (s, theta) -> Loopingprofile (bild/amis.py:670-695) """
         T = len(self.traj)
         states = theta[0] * np.ones(T)
         if len(s) > 1:
-            switches = switch_indices(np.asarray(s)[None, :], T)[0]
+            switches = switch_indices(np.asarray(s, dtype=np.float64)[None, :], T)[0]
             for i in range(1, len(switches)):
                 states[switches[i - 1]:switches[i]] = theta[i]
             states[switches[-1]:] = theta[-1]
         return Loopingprofile(states)
 
+    # -- densities --------------------------------------------------------------------------
+    def log_proposal(self, parameters, ss, thetas):
+        """ log density of the product proposal (bild/amis.py:697-715) """
+        return self.dirichlet.logpdf(parameters[0], ss) + self.cfc.logpmf(parameters[1], thetas)
+
     def logL(self, ss, thetas):
         """
-        Evaluate the model likelihood for a batch (reference bild/amis.py:717-739).
-
-        ss : (N, k+1) float64 ; thetas : (N, k+1) int  ->  (N,) float64
+        Model likelihood of a batch (bild/amis.py:717-739): ss (N, k+1) float, thetas (N, k+1)
+        int -> (N,) float64.
         """
         ss = np.asarray(ss, dtype=np.float64)
         thetas = np.asarray(thetas)
@@ -71,3 +328,143 @@ class FixedkSampler:
         else:
             return np.array([self.model.logL(self.st2profile(s, theta), self.traj)
                              for s, theta in zip(ss, thetas)])
+
+    # -- exhaustive evaluation ----------------------------------------------------------------
+    def fix_exhaustive(self):
+        """
+        Evaluate every profile when there are few enough (bild/amis.py:741-803); the evidence
+        is then exact (``dlogev`` is set to 1e-10) and the sampler is marked exhausted.
+        """
+        T = len(self.traj)
+        Nmax = min(self.max_fcomplete, self.max_fev)
+        Nprofiles = self.cfc.N_total(self.k)
+        for i in range(self.k):
+            Nprofiles *= T - i - 1
+            if Nprofiles > Nmax:
+                raise self.ExhaustionImpractical(
+                    f"Parameter space too large for exhaustive sampling (number of profiles = {Nprofiles} > Nmax = {Nmax})")
+
+        # switch positions at half-integer frames, as fractions of the trajectory
+        combos = np.array(list(itertools.combinations(np.arange(T - 1) + 0.5, self.k))) / (T - 1)  # (n_ss, k)
+        edges = np.concatenate([np.zeros((len(combos), 1)), combos, np.ones((len(combos), 1))], axis=1)
+        ss_unique = np.diff(edges, axis=1)
+        thetas_unique = self.cfc.full_sample(self.k, Nmax=Nmax)
+
+        n_ss = len(ss_unique)
+        ss = np.tile(ss_unique, (len(thetas_unique), 1))
+        thetas = np.repeat(thetas_unique, n_ss, axis=0)
+
+        sample = {'ss': ss, 'thetas': thetas}
+        sample['logLs'] = self.logL(ss, thetas)
+        self.samples.append(sample)
+
+        # evidence = mean likelihood under the (uniform) prior ensemble; KL(posterior || prior)
+        top = np.max(sample['logLs'])
+        with np.errstate(under='ignore'):
+            rel = np.exp(sample['logLs'] - top)
+        ev = np.mean(rel)
+        logev = np.log(ev) + top
+        with np.errstate(under='ignore'):
+            KL = np.mean(sample['logLs'] * rel) / ev - logev
+        self.evidences.append((logev, 1e-10, KL))
+        self.exhausted = True
+
+    # -- one AMIS iteration ---------------------------------------------------------------------
+    def step(self):
+        """
+        One AMIS iteration (bild/amis.py:805-906).  Returns ``False`` (and does nothing) when
+        the sampler is exhausted, else ``True``.
+        """
+        if self.exhausted:
+            return False
+
+        a_cur, logp_cur = self.parameters[-1]
+
+        # the mixture denominator of every earlier sample gains the current proposal
+        for old in self.samples:
+            old['cur_log_proposal'] = self.log_proposal(self.parameters[-1], old['ss'], old['thetas'])
+            with np.errstate(under='ignore'):
+                old['logδs'] = np.logaddexp(old['logδs'], old['cur_log_proposal'])
+
+        new = {
+            'ss': self.dirichlet.sample(a_cur, self.N),
+            'thetas': self.cfc.sample(logp_cur, self.N),
+        }
+        new['logLs'] = self.logL(new['ss'], new['thetas'])
+        new['cur_log_proposal'] = self.log_proposal(self.parameters[-1], new['ss'], new['thetas'])
+        with np.errstate(under='ignore'):
+            new['logδs'] = logsumexp([self.log_proposal(par, new['ss'], new['thetas']) for par in self.parameters[:-1]]
+                                     + [new['cur_log_proposal']], axis=0)
+        self.samples.append(new)
+
+        # deterministic-mixture weights: L / mean over proposals
+        log_nprop = np.log(len(self.parameters))
+        for smp in self.samples:
+            smp['log_weights'] = smp['logLs'] - smp['logδs'] + log_nprop
+
+        pooled = {key: np.concatenate([smp[key] for smp in self.samples], axis=0) for key in self.samples[-1]}
+
+        # refit, then brake
+        new_a = self.dirichlet.estimate(pooled['ss'], pooled['log_weights'])
+        new_logp = self.cfc.estimate(pooled['thetas'], pooled['log_weights'])
+
+        limit_c = self.N * self.brakes[0]
+        log_ratio = np.log(np.sum(new_a) / np.sum(a_cur))
+        if np.abs(log_ratio) > limit_c:
+            new_a = new_a * np.exp(np.sign(log_ratio) * limit_c - log_ratio)
+
+        limit_p = self.N * self.brakes[1]
+        with np.errstate(under='ignore'):
+            p_old = np.exp(logp_cur)
+            p_new = np.exp(new_logp)
+        for i in range(p_new.shape[1]):
+            delta = p_new[:, i] - p_old[:, i]
+            biggest = np.max(np.abs(delta))
+            if biggest > limit_p:
+                with np.errstate(divide='ignore'):
+                    new_logp[:, i] = np.log(p_old[:, i] + limit_p * delta / biggest)
+
+        self.parameters.append((new_a, new_logp))
+
+        # evidence, its standard error, and KL(posterior || current proposal)
+        top = np.max(pooled['log_weights'])
+        with np.errstate(under='ignore'):
+            rel = np.exp(pooled['log_weights'] - top)
+        ev = np.mean(rel)
+        logev = np.log(ev) + top + self.logprior
+        dlogev = stats.sem(rel) / ev
+        with np.errstate(under='ignore', invalid='ignore'):
+            # zero-weight samples with cur_log_proposal = -inf give nan terms: dropped from the
+            # sum but kept in the normalisation (bild/amis.py:883-898)
+            KL = (np.nansum(rel * (pooled['logLs'] - pooled['cur_log_proposal'])) / len(rel) / ev
+                  - logev + self.logprior)
+        self.evidences.append((logev, dlogev, KL))
+
+        if (len(self.samples) + 1) * self.N >= self.max_fev:
+            self.exhausted = True
+        return True
+
+    # -- summaries ----------------------------------------------------------------------------------
+    def tstat(self, other):
+        """ evidence separation from another sampler in units of the combined standard error (bild/amis.py:908-926) """
+        logev0, dlogev0 = self.evidences[-1][:2]
+        logev1, dlogev1 = other.evidences[-1][:2]
+        return (logev0 - logev1) / np.sqrt(dlogev0 ** 2 + dlogev1 ** 2)
+
+    def MAP_profile(self):
+        """ the sampled profile of highest likelihood (bild/amis.py:928-943) """
+        best_in = [int(np.argmax(smp['logLs'])) for smp in self.samples]
+        best_val = [smp['logLs'][i] for smp, i in zip(self.samples, best_in)]
+        j = int(np.argmax(best_val))
+        return self.st2profile(self.samples[j]['ss'][best_in[j]], self.samples[j]['thetas'][best_in[j]])
+
+    def log_marginal_posterior(self):
+        """ (n, T) normalised log posterior marginals of the state at each frame (bild/amis.py:945-972) """
+        pooled = {key: np.concatenate([smp[key] for smp in self.samples]) for key in self.samples[-1]}
+        log_weights = pooled['log_weights'] if 'log_weights' in pooled else pooled['logLs']
+        all_states = np.stack([self.st2profile(s, t)[:] for s, t in zip(pooled['ss'], pooled['thetas'])])  # (N, T)
+        n = self.model.nStates
+        hit = all_states[:, None, :] == np.arange(n)[None, :, None]
+        logpost = _masked_logsumexp(log_weights[:, None, None], hit, axis=0)
+        with np.errstate(under='ignore'):
+            return logpost - logsumexp(logpost, axis=0)

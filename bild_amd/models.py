@@ -253,3 +253,64 @@ class MultiStateRouse(MultiStateModel):
         data[missing, :] = np.nan
         data += localization_error[None, :] * rng.standard_normal(data.shape)
         return Trajectory(data, localization_error=localization_error, loopingprofile=profile)
+
+
+class FactorizedModel(MultiStateModel):
+    """
+    Time-scale-separated stand-in likelihood: every frame is drawn independently from the
+    distance distribution of its state (reference bild/models.py:372-534).  Cheap, CPU only;
+    the reference's own tests use it as the likelihood double for everything above the kernel,
+    and so do this package's sampler tests.
+
+    distributions : objects with ``logpdf(r)`` (e.g. ``scipy.stats.maxwell(scale=...)``)
+    """
+
+    def __init__(self, distributions, d=3):
+        self.distributions = distributions
+        self._d = d
+        self._tables = {}
+        self.init_transitions(len(distributions))
+
+    @property
+    def d(self):
+        return self._d
+
+    def clear_memo(self):
+        self._tables = {}
+
+    def _table(self, traj):
+        key = id(traj)
+        hit = self._tables.get(key)
+        if hit is None or hit[0] is not traj:
+            arr = as_array(traj)
+            r = np.sqrt(np.sum(arr ** 2, axis=1))
+            with np.errstate(divide='ignore', invalid='ignore'):
+                table = np.array([dist.logpdf(r) for dist in self.distributions])  # (n, T), NaN on missing frames
+            hit = (traj, table)
+            self._tables[key] = hit
+        return hit[1]
+
+    def initial_loopingprofile(self, traj):
+        """ per-frame maximum-likelihood state, missing frames filled from the next valid one """
+        table = self._table(traj)
+        valid = np.nonzero(~np.any(np.isnan(as_array(traj)), axis=1))[0]
+        best = np.argmax(table[:, valid], axis=0)
+        states = np.zeros(len(traj), dtype=int)
+        states[:valid[0] + 1] = best[0]
+        last = valid[0]
+        for t, s in zip(valid[1:], best[1:]):
+            states[last + 1:t + 1] = s
+            last = t
+        states[last + 1:] = best[-1]
+        return Loopingprofile(states)
+
+    def logL(self, profile, traj):
+        table = self._table(traj)
+        states = np.asarray(profile[:], dtype=int)
+        return float(np.nansum(table[states, np.arange(len(states))]))
+
+    def logL_batch(self, profiles, traj):
+        table = self._table(traj)
+        if not isinstance(profiles, np.ndarray):
+            profiles = np.stack([np.asarray(p[:]) for p in profiles])
+        return np.nansum(table[profiles, np.arange(profiles.shape[1])[None, :]], axis=1)

@@ -39,6 +39,11 @@ class Trajectory:
     def __getitem__(self, key):
         return self.data[key]
 
+    def abs(self):
+        """ trajectory of the Euclidean norm per frame, (T, 1) (noctiluca ``Trajectory.abs()``) """
+        return Trajectory(np.sqrt(np.sum(self.data ** 2, axis=1, keepdims=True)),
+                          localization_error=None, loopingprofile=self.meta.get('loopingprofile'))
+
     def valid_frames(self):
         return ~np.any(np.isnan(self.data), axis=1)
 
