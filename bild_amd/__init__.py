@@ -10,7 +10,8 @@ One hot path, behind the reference's own interfaces:
 both evaluated by hand-written HIP kernels for gfx950 through the C ABI declared in
 ``include/bild_amd.h`` (``bild_amd/libbild_amd.so``).  There is no CPU fallback.
 """
-from . import rouse, profiles, util, trajectory, models, amis  # noqa: F401
+from . import rouse, profiles, util, trajectory, models, amis, choicesampler, core, postproc  # noqa: F401
+from .core import sample, sample_many, SamplingResults  # noqa: F401
 from .models import MultiStateModel, MultiStateRouse, FactorizedModel  # noqa: F401
 from .amis import FixedkSampler, Dirichlet, CFC  # noqa: F401
 from .profiles import Loopingprofile  # noqa: F401

@@ -57,3 +57,17 @@ def as_array(traj):
     if arr.ndim == 1:
         arr = arr[:, None]
     return np.ascontiguousarray(arr)
+
+
+def make_trajectory(traj):
+    """
+    Accept what reference ``bild.sample`` accepts on its first argument as far as the likelihood
+    path needs it (the reference delegates to ``noctiluca.make_Trajectory``, bild/core.py:111):
+    anything trajectory-like is passed through, arrays of shape (T,) or (T, d) are wrapped.
+    """
+    if isinstance(traj, np.ndarray) or isinstance(traj, (list, tuple)):
+        arr = np.asarray(traj, dtype=np.float64)
+        if arr.ndim > 2:
+            raise ValueError("pass the (T, d) distance trajectory of one pair of loci")
+        return Trajectory(arr)
+    return traj

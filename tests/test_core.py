@@ -1,0 +1,164 @@
+"""
+CPU tests of the rows around the sampler:
+
+* `ChoiceSampler` against golden vectors from the reference's own module (fixed seed: exact);
+* `core.sample` / `SamplingResults`: the statistical pins of reference tests/test_bild.py:224-283
+  (its `TestCore`), with `FactorizedModel` as the likelihood, exactly as there;
+* `postproc`: the exact pins of reference tests/test_bild.py:302-321;
+* `sample_many`: the fused, deterministic execution gives the same results as sequential runs.
+"""
+import os
+
+import numpy as np
+import pytest
+from scipy import stats
+from scipy.special import logsumexp
+
+import bild_amd
+from bild_amd import postproc
+from bild_amd.choicesampler import ChoiceSampler
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.mark.parametrize('name', ['peaked', 'margin', 'flat'])
+def test_choicesampler_matches_reference(name):
+    g = np.load(os.path.join(HERE, 'golden', 'choicesampler.npz'))
+    np.random.seed(int(g[f'{name}_seed']))
+    cs = ChoiceSampler(g[f'{name}_muhat'], g[f'{name}_shat'], g[f'{name}_N'], float(g[f'{name}_dE']), samplesize=4000)
+    assert np.array_equal(cs.n0, g[f'{name}_n0'])
+    assert np.array_equal(cs.bestk, g[f'{name}_bestk'])
+    assert np.array_equal(cs.Dn(), g[f'{name}_Dn'])
+    assert np.allclose(cs.KLD_moreSamples(), g[f'{name}_KLD'], rtol=1e-13, atol=0)
+    assert np.isclose(cs.KLD_omitK(g[f'{name}_omit']), float(g[f'{name}_Ila']), rtol=1e-13, atol=0)
+
+
+@pytest.fixture
+def toy():
+    traj = bild_amd.Trajectory([0.1, 0.05, 6, 3, 4, 0.01, 5, 7])
+    model = bild_amd.FactorizedModel([stats.maxwell(scale=0.1), stats.maxwell(scale=1)])
+    return traj, model
+
+
+def _normalised(logpost):
+    return np.allclose(logsumexp(logpost, axis=0), 0, atol=1e-10)
+
+
+def test_sample_pins(toy):
+    traj, model = toy
+    np.random.seed(685441950)
+    for _ in range(5):
+        res = bild_amd.sample(traj, model, init_runs=5, sampler_kw={'max_fev': 1000})
+        assert len(res.k) > 4
+        assert np.argmax(res.evidence) >= 3
+        assert np.all(res.evidence_se > 0)
+        assert np.array_equal(res.best_profile()[:], res.best_profile(dE=2)[:])
+    assert _normalised(res.log_marginal_posterior())
+    assert _normalised(res.log_marginal_posterior(dE=2))
+    assert _normalised(res.log_marginal_posterior(dE='average'))
+    assert res.log['k'].ndim == 1 and res.log['pk'].ndim == 2 and res.log['pk'].shape[0] == len(res.log['k'])
+
+
+@pytest.mark.parametrize('extra', [dict(k_lookahead=5), dict(k_lookahead=5, k_max=3)])
+def test_sample_lookahead_and_small_kmax(toy, extra):
+    traj, model = toy
+    np.random.seed(1)
+    for _ in range(3):
+        res = bild_amd.sample(traj, model, init_runs=5, sampler_kw={'N': 10, 'max_fev': 100, 'max_fcomplete': 10}, **extra)
+    if 'k_max' in extra:
+        assert len(res.k) <= extra['k_max'] + 1
+    assert _normalised(res.log_marginal_posterior())
+    assert _normalised(res.log_marginal_posterior(dE=2))
+
+
+def test_sample_accepts_arrays(toy):
+    _, model = toy
+    np.random.seed(2)
+    res = bild_amd.sample(np.array([0.1, 0.05, 6, 3, 4, 0.01, 5, 7]), model, init_runs=3, sampler_kw={'max_fev': 300})
+    assert len(res.traj) == 8 and res.best_k() >= 0
+
+
+def test_postproc_pins(toy):
+    traj, model = toy
+    bad = bild_amd.Loopingprofile([0, 1, 1, 1, 0, 0, 0, 1])
+    better = postproc.optimize_boundary(bad, traj, model)
+    assert np.array_equal(better[:], [0, 0, 1, 1, 1, 0, 1, 1])
+    assert np.array_equal(bad[:], [0, 1, 1, 1, 0, 0, 0, 1])          # input untouched
+    with pytest.raises(RuntimeError):
+        postproc.optimize_boundary(bad, traj, model, max_iteration=2)   # three moves are needed
+    with pytest.raises(postproc.BoundaryEliminationError):
+        postproc.optimize_boundary(bild_amd.Loopingprofile([0, 1, 0, 1, 0, 0, 0, 1]), traj, model)
+    flat = bild_amd.Loopingprofile([1] * 8)
+    assert np.array_equal(postproc.optimize_boundary(flat, traj, model, max_iteration=1)[:], [1] * 8)
+    lr = postproc.logLR_boundaries(bad, traj, model)
+    assert lr.shape == (3, 2)
+    # one-at-a-time evaluation (the reference's way) gives the same ratios as the batch
+    class OneByOne:
+        transitions, nStates, d = model.transitions, model.nStates, model.d
+
+        def logL(self, profile, tr):
+            return model.logL(profile, tr)
+    assert np.allclose(postproc.logLR_boundaries(bad, traj, OneByOne()), lr, rtol=0, atol=1e-12)
+
+
+class _SegmentTableModel:
+    """ table likelihood offering the fused entry point `sample_many` needs """
+
+    def __init__(self, tables):
+        self.tables = tables
+        self.transitions = ~np.eye(2, dtype=bool)
+        self.nStates, self.d = 2, 1
+        self.launches = 0
+
+    def _one(self, table, seg_start, seg_state):
+        T = table.shape[1]
+        states = np.empty(T, dtype=int)
+        states[:] = seg_state[0]
+        for a, s in zip(seg_start[1:], seg_state[1:]):
+            if a < T:
+                states[a:] = s
+        return float(np.sum(table[states, np.arange(T)]))
+
+    def logL_st_batch(self, ss, thetas, traj):
+        from bild_amd.profiles import segments_from_st
+        a, b = segments_from_st(ss, thetas, len(traj))
+        table = self.tables[int(traj[0, 0])]
+        return np.array([self._one(table, x, y) for x, y in zip(a, b)])
+
+    def logL(self, profile, traj):
+        table = self.tables[int(traj[0, 0])]
+        return float(np.sum(table[np.asarray(profile[:], dtype=int), np.arange(len(profile))]))
+
+    def logL_segments(self, seg_start, seg_state, trajs, traj_id):
+        self.launches += 1
+        return np.array([self._one(self.tables[j], a, b) for a, b, j in zip(seg_start, seg_state, traj_id)])
+
+
+def test_sample_many_is_fused_and_deterministic():
+    from amis_cases import _table
+    tables = [_table(30 + j, 2, 12 + 3 * j, [4 + j, 9 + j]) for j in range(4)]
+    # a trajectory here only has to identify its table (first entry) and have the right length
+    trajs = [bild_amd.Trajectory(np.full((t.shape[1], 1), float(j))) for j, t in enumerate(tables)]
+    kw = dict(init_runs=3, k_max=4, sampler_kw={'N': 20, 'max_fev': 200, 'max_fcomplete': 30}, choice_kw={'samplesize': 500})
+
+    model = _SegmentTableModel(tables)
+    np.random.seed(77)
+    fused_a = bild_amd.sample_many(trajs, model, **kw)
+    launches = model.launches
+    np.random.seed(77)
+    fused_b = bild_amd.sample_many(trajs, model, **kw)
+    total_steps = sum(len(s.samples) for r in fused_a for s in r.samplers)
+    assert launches < total_steps                      # batches of different trajectories were fused
+    for ra, rb in zip(fused_a, fused_b):               # same seed -> identical runs
+        assert np.array_equal(ra.evidence, rb.evidence) and np.array_equal(ra.log['k'], rb.log['k'])
+    for j, r in enumerate(fused_a):                    # every result is a valid inference of its trajectory
+        assert len(r.traj) == tables[j].shape[1]
+        assert np.all(np.isfinite(r.evidence[:2]))
+        assert _normalised(r.log_marginal_posterior())
+        assert r.best_profile()[:].shape == (tables[j].shape[1],)
+    # errors inside a task surface in the caller
+    class Broken(_SegmentTableModel):
+        def logL_segments(self, *a):
+            raise FloatingPointError("boom")
+    with pytest.raises(FloatingPointError):
+        bild_amd.sample_many(trajs, Broken(tables), **kw)

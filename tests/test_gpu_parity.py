@@ -182,3 +182,72 @@ def test_error_paths(built_lib):
     with pytest.raises(AssertionError):        # wrong spatial dimension (reference asserts shapes, pyx:165-166)
         model.logL_batch(np.zeros((1, 10), int), bild_amd.Trajectory(np.zeros((10, 3))))
     assert model.logL_batch(np.zeros((0, 10), int), traj).shape == (0,)
+
+
+class _OracleRouse:
+    """ CPU stand-in with the reference kernel semantics (oracle), for end-to-end comparisons """
+
+    def __init__(self, model):
+        self.m = model
+        self.transitions, self.nStates, self.d = model.transitions, model.nStates, model.d
+
+    def logL(self, profile, traj):
+        from oracle import oracle
+        return oracle.logl(self.m.arrays(), self.m.measurement, self.m._get_noise(traj), traj[:], np.asarray(profile[:]))
+
+
+def test_amis_steps_gpu_equal_cpu_oracle(built_lib):
+    """ whole AMIS iterations: GPU likelihood vs oracle likelihood, same random stream """
+    import bild_amd
+    rng = np.random.default_rng(3)
+    T = 60
+    model = bild_amd.MultiStateRouse(20, 1, 5, d=3, localization_error=0.1)
+    truth = H.random_profile(rng, T, 2, 20)
+    traj = model.trajectory_from_loopingprofile(truth, missing_frames=0.05, rng=rng)
+    runs = []
+    for mdl in (model, _OracleRouse(model)):
+        np.random.seed(99)
+        sampler = bild_amd.FixedkSampler(traj, mdl, k=2, N=50, max_fcomplete=10)
+        for _ in range(3):
+            assert sampler.step()
+        runs.append(sampler)
+    a, b = runs
+    for sa, sb in zip(a.samples, b.samples):
+        assert np.array_equal(sa['thetas'], sb['thetas'])
+        assert np.max(np.abs(sa['logLs'] - sb['logLs'])) < TOL
+    assert np.allclose(np.array(a.evidences), np.array(b.evidences), rtol=0, atol=1e-7)
+    assert np.array_equal(a.MAP_profile()[:], b.MAP_profile()[:])
+
+
+def test_sample_many_and_postproc_gpu(built_lib):
+    """ config-5 style: the adaptive-k loop for several trajectories with fused launches, then boundary polishing """
+    import bild_amd
+    from bild_amd import postproc
+    rng = np.random.default_rng(8)
+    model = bild_amd.MultiStateRouse(20, 1, 5, d=3, localization_error=0.1)
+    trajs, truths = [], []
+    for T in (40, 55, 70):
+        truth = H.random_profile(rng, T, 2, 18)
+        truths.append(truth)
+        trajs.append(model.trajectory_from_loopingprofile(truth, rng=rng))
+    kw = dict(init_runs=3, k_max=4, sampler_kw={'N': 40, 'max_fev': 800, 'max_fcomplete': 50}, choice_kw={'samplesize': 1000})
+    np.random.seed(5)
+    fused = bild_amd.sample_many(trajs, model, **kw)
+    np.random.seed(5)
+    again = bild_amd.sample_many(trajs, model, **kw)
+    oracle_model = _OracleRouse(model)
+    for res, res2, traj in zip(fused, again, trajs):
+        assert np.array_equal(res.evidence, res2.evidence)           # deterministic
+        assert np.all(np.isfinite(res.evidence[:3]))
+        prof = res.best_profile()
+        # GPU single-profile likelihood == oracle on the inferred profile
+        assert abs(model.logL(prof, traj) - oracle_model.logL(prof, traj)) < TOL
+        # boundary polishing (2k+1 profiles per iteration as one GPU batch) agrees with the CPU oracle
+        try:
+            pg = postproc.optimize_boundary(prof, traj, model)
+            pc = postproc.optimize_boundary(prof, traj, oracle_model)
+            assert pg == pc
+            assert model.logL(pg, traj) >= model.logL(prof, traj) - 1e-9
+        except postproc.BoundaryEliminationError:
+            with pytest.raises(postproc.BoundaryEliminationError):
+                postproc.optimize_boundary(prof, traj, oracle_model)
