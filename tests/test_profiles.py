@@ -36,13 +36,15 @@ def test_state_probabilities():
     assert state_probabilities(profs, nStates=3).shape == (3, 3)
 
 
-class _FakeModel:
-    nStates = 2
+def _FakeModel(T=None, n=3):
+    """ likelihood double: the sampler's constructor may evaluate profiles exhaustively """
+    from amis_cases import TableModel
+    return TableModel(np.zeros((n, 400)))
 
 
 def test_st2profile_reference_pin():
     # reference tests/test_amis.py:199-202: st2profile([.25,.5,.25],[0,1,0]) on T=6 -> [0,0,1,1,0,0]
-    sampler = FixedkSampler(np.zeros((6, 1)), _FakeModel(), k=2)
+    sampler = FixedkSampler(np.zeros((6, 1)), _FakeModel(), k=2, max_fcomplete=0)
     prof = sampler.st2profile(np.array([0.25, 0.5, 0.25]), np.array([0, 1, 0]))
     assert np.array_equal(prof[:], [0, 0, 1, 1, 0, 0])
     assert isinstance(prof, Loopingprofile) and prof.state.dtype.kind == 'i'
@@ -59,7 +61,7 @@ def test_segments_match_st2profile_semantics():
             if k >= 2:
                 ss[1, 1] = 0.0
                 ss[1] /= ss[1].sum()
-            sampler = FixedkSampler(np.zeros((T, 1)), _FakeModel(), k=k)
+            sampler = FixedkSampler(np.zeros((T, 1)), _FakeModel(), k=k, max_fcomplete=(1000 if k == 0 else 3))
             seg_start, seg_state = segments_from_st(ss, thetas, T)
             assert seg_start.dtype == np.int32 and np.all(seg_start[:, 0] == 0)
             assert np.all(np.diff(seg_start, axis=1) >= 0) and np.all(seg_start[:, 1:] >= 1)
