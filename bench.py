@@ -94,6 +94,7 @@ def main():
     ap.add_argument('--states', type=int, default=2)
     ap.add_argument('--path', default='auto', choices=['auto', 'modal', 'dense'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-reduce', action='store_true', help='keep all N modes (skip the invariant-subspace reduction)')
     ap.add_argument('--no-dense', action='store_true', help='skip the secondary dense-path measurement')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help="collective backend; 'gloo' (log-likelihoods staged through host memory) rehearses the "
@@ -134,6 +135,9 @@ def main():
     n, T, k = args.samples, args.T, args.k
     model, traj, ss, thetas = build_workload(rank, n, T, k, S=args.states)
     model.path = args.path
+    if args.no_reduce:
+        a_ = model.arrays()
+        model._handle = _lib.ModelHandle(a_['B'], a_['G'], a_['Sig'], a_['M0'], a_['C0'], model.measurement, reduce=False)
     h = model.handle()
     ts = model.trajset(traj)                          # trajectory resident in HBM
     seg_start, seg_state = segments_from_st(ss, thetas, T)

@@ -440,20 +440,28 @@ int launch_geom(int mode, const KParams &p, int grid, size_t lds, hipStream_t st
 // (id, rows, columns per lane, lanes per group, waves per workgroup, min waves per SIMD);
 // CPL * G >= NP + 3.  W is chosen so that W * (64/G) group images + the dense tables fit in
 // 160 KiB of LDS; OCC bounds the register allocation (512 / OCC VGPRs per lane).  The table
-// may hold several geometries per NP (geometry_for picks by batch size); measured on MI355X
-// for NP = 10, (CPL, G) = (3, 5) and (5, 3) -- fewer lanes per task, fewer instructions per
-// task -- lose to (2, 8) at every batch size because they run at one wave per SIMD with a
-// longer dependent chain per frame (profiles/r01_geometry_sweep.txt), so one entry per NP.
+// may hold several geometries per NP, listed by increasing tasks per wave: geometry_for takes
+// the first one that puts at most one wave on every SIMD, else the last (densest) one.
+// Measured on MI355X (profiles/r01_geometry_sweep.txt):
+//  * NP = 10: (CPL, G) = (3, 5) and (5, 3) -- fewer lanes per task, fewer instructions per
+//    task -- lose to 2 columns per lane at every batch size: they run at one wave per SIMD
+//    with a longer dependent chain per frame.  (2, 7) beats (2, 8): 9 instead of 8 tasks per
+//    wave at the same instruction count (13 of 14 column slots used).
+//  * NP = 16 / 20: forcing two waves per SIMD (OCC = 2, with or without the predict-factor
+//    table) spills inside the frame loop and is 4-6x slower; 2 columns per lane wins for
+//    batches up to ~1000 waves, 3 columns per lane beyond.
 #define BILD_GEOMETRIES(X)  \
     X(0, 4, 2, 4, 4, 2)     \
     X(1, 8, 3, 4, 4, 2)     \
     X(2, 10, 2, 7, 4, 2)    \
     X(3, 12, 2, 8, 4, 2)    \
-    X(4, 16, 3, 7, 4, 1)    \
-    X(5, 20, 3, 8, 4, 1)    \
-    X(6, 24, 4, 8, 2, 1)    \
-    X(7, 28, 4, 8, 2, 1)    \
-    X(8, 32, 3, 16, 2, 1)
+    X(4, 16, 2, 10, 4, 1)   \
+    X(5, 16, 3, 7, 4, 1)    \
+    X(6, 20, 2, 12, 4, 1)   \
+    X(7, 20, 3, 8, 4, 1)    \
+    X(8, 24, 4, 8, 2, 1)    \
+    X(9, 28, 4, 8, 2, 1)    \
+    X(10, 32, 3, 16, 2, 1)
 
 constexpr Geometry kGeoms[] = {
 #define X(ID, NP, CPL, G, W, OCC) {NP, CPL, G, W, OCC, ID},
