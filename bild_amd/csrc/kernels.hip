@@ -441,27 +441,33 @@ int launch_geom(int mode, const KParams &p, int grid, size_t lds, hipStream_t st
 // CPL * G >= NP + 3.  W is chosen so that W * (64/G) group images + the dense tables fit in
 // 160 KiB of LDS; OCC bounds the register allocation (512 / OCC VGPRs per lane).  The table
 // may hold several geometries per NP, listed by increasing tasks per wave: geometry_for takes
-// the first one that puts at most one wave on every SIMD, else the last (densest) one.
+// the first one whose waves are all resident at once, else the last (densest) one.
 // Measured on MI355X (profiles/r01_geometry_sweep.txt):
 //  * NP = 10: (CPL, G) = (3, 5) and (5, 3) -- fewer lanes per task, fewer instructions per
 //    task -- lose to 2 columns per lane at every batch size: they run at one wave per SIMD
 //    with a longer dependent chain per frame.  (2, 7) beats (2, 8): 9 instead of 8 tasks per
 //    wave at the same instruction count (13 of 14 column slots used).
+//    One column per lane (1, 13) at three waves per SIMD has the shortest frame latency
+//    (0.28 us vs 0.46 us per frame for a lone wave) and wins up to ~12k tasks; (2, 7) beyond.
 //  * NP = 16 / 20: forcing two waves per SIMD (OCC = 2, with or without the predict-factor
 //    table) spills inside the frame loop and is 4-6x slower; 2 columns per lane wins for
 //    batches up to ~1000 waves, 3 columns per lane beyond.
 #define BILD_GEOMETRIES(X)  \
     X(0, 4, 2, 4, 4, 2)     \
     X(1, 8, 3, 4, 4, 2)     \
-    X(2, 10, 2, 7, 4, 2)    \
-    X(3, 12, 2, 8, 4, 2)    \
-    X(4, 16, 2, 10, 4, 1)   \
-    X(5, 16, 3, 7, 4, 1)    \
-    X(6, 20, 2, 12, 4, 1)   \
-    X(7, 20, 3, 8, 4, 1)    \
-    X(8, 24, 4, 8, 2, 1)    \
-    X(9, 28, 4, 8, 2, 1)    \
-    X(10, 32, 3, 16, 2, 1)
+    X(2, 10, 1, 13, 4, 3)   \
+    X(3, 10, 2, 7, 4, 2)    \
+    X(4, 12, 1, 15, 4, 3)   \
+    X(5, 12, 2, 8, 4, 2)    \
+    X(6, 16, 1, 19, 4, 2)   \
+    X(7, 16, 2, 10, 4, 1)   \
+    X(8, 16, 3, 7, 4, 1)    \
+    X(9, 20, 1, 23, 4, 2)   \
+    X(10, 20, 2, 12, 4, 1)  \
+    X(11, 20, 3, 8, 4, 1)   \
+    X(12, 24, 4, 8, 2, 1)   \
+    X(13, 28, 4, 8, 2, 1)   \
+    X(14, 32, 3, 16, 2, 1)
 
 constexpr Geometry kGeoms[] = {
 #define X(ID, NP, CPL, G, W, OCC) {NP, CPL, G, W, OCC, ID},
@@ -469,6 +475,7 @@ constexpr Geometry kGeoms[] = {
 #undef X
 };
 constexpr int kNumGeoms = sizeof(kGeoms) / sizeof(kGeoms[0]);
+constexpr int kFirstExperimental = 15; // ids from here on are only reachable through BILD_GEOM
 
 } // namespace
 
@@ -488,14 +495,14 @@ bool geometry_for(int NP, int64_t ntasks, Geometry *g)
             return true;
         }
     }
-    // candidates are listed by increasing tasks per wave: take the first one that still puts at
-    // most one wave on every SIMD (256 CUs x 4), else the densest
+    // candidates are listed by increasing tasks per wave: take the first one whose waves are all
+    // resident at once (256 CUs x 4 SIMDs x OCC waves), else the densest
     const Geometry *best = nullptr;
     for (const Geometry &c : kGeoms) {
-        if (c.NP != NP) continue;
+        if (c.NP != NP || c.id >= kFirstExperimental) continue;
         best = &c;
         const int64_t waves = (ntasks + c.tasks_per_wave() - 1) / c.tasks_per_wave();
-        if (waves <= 1024) break;
+        if (waves <= 1024 * (int64_t)c.OCC) break;
     }
     if (!best) return false;
     *g = *best;
