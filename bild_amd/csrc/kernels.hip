@@ -53,6 +53,10 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// log() is needed once per task; out of line, so that its polynomial constants are not hoisted
+// out of the task loop into registers the frame loop then has to spill around.
+__device__ __attribute__((noinline)) double log_once(double x) { return log(x); }
+
 template <int NP, int CPL>
 struct Cols {
     double v[CPL][NP];
@@ -66,26 +70,38 @@ template <int NP, int CPL, typename XPtr>
 __device__ __forceinline__ void matvec_to_lds(XPtr X, const Cols<NP, CPL> &in, double *__restrict__ Tg,
                                               const int (&cidx)[CPL], const bool (&store)[CPL])
 {
+    // rows per trip: two give each X operand pair 2*CPL independent FMAs; with a single column per
+    // lane one row at a time keeps the operand registers of this (rare) path out of the budget of
+    // the frame loop
+    constexpr int R = (CPL == 1) ? 1 : 2;
 #pragma unroll 1
-    for (int i = 0; i < NP; i += 2) {
-        double a0[CPL], a1[CPL];
+    for (int i = 0; i < NP; i += R) {
+        double a[R][CPL];
 #pragma unroll
-        for (int q = 0; q < CPL; ++q) a0[q] = a1[q] = 0.0;
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) a[r][q] = 0.0;
 #pragma unroll
         for (int k = 0; k < NP; k += 2) {
-            const double2 x0 = *reinterpret_cast<const double2 *>(X + i * NP + k);
-            const double2 x1 = *reinterpret_cast<const double2 *>(X + (i + 1) * NP + k);
+            double2 x[R];
 #pragma unroll
-            for (int q = 0; q < CPL; ++q) {
-                a0[q] = fma(x0.x, in.v[q][k], a0[q]);
-                a1[q] = fma(x1.x, in.v[q][k], a1[q]);
-                a0[q] = fma(x0.y, in.v[q][k + 1], a0[q]);
-                a1[q] = fma(x1.y, in.v[q][k + 1], a1[q]);
-            }
+            for (int r = 0; r < R; ++r) x[r] = *reinterpret_cast<const double2 *>(X + (i + r) * NP + k);
+#pragma unroll
+            for (int q = 0; q < CPL; ++q)
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    a[r][q] = fma(x[r].x, in.v[q][k], a[r][q]);
+                    a[r][q] = fma(x[r].y, in.v[q][k + 1], a[r][q]);
+                }
         }
 #pragma unroll
         for (int q = 0; q < CPL; ++q)
-            if (store[q]) *reinterpret_cast<double2 *>(Tg + cidx[q] * NP + i) = make_double2(a0[q], a1[q]);
+            if (store[q]) {
+                if (R == 2)
+                    *reinterpret_cast<double2 *>(Tg + cidx[q] * NP + i) = make_double2(a[0][q], a[R - 1][q]);
+                else
+                    Tg[cidx[q] * NP + i] = a[0][q];
+            }
     }
 }
 
@@ -402,7 +418,7 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
             double tot = 0.0;
 #pragma unroll
             for (int g2 = 0; g2 < G; ++g2) tot += scratch[g2];
-            const double logS = log(P) + (double)E * kLn2;
+            const double logS = log_once(P) + (double)E * kLn2;
             tot += (double)nd * (logS + (double)td->nvalid * kLog2Pi);
             p.out[task] = -0.5 * tot;
         }
@@ -457,7 +473,7 @@ int launch_geom(int mode, const KParams &p, int grid, size_t lds, hipStream_t st
     X(1, 8, 3, 4, 4, 2)     \
     X(2, 10, 1, 13, 4, 3)   \
     X(3, 10, 2, 7, 4, 2)    \
-    X(4, 12, 1, 15, 4, 3)   \
+    X(4, 12, 1, 15, 4, 2)   \
     X(5, 12, 2, 8, 4, 2)    \
     X(6, 16, 1, 19, 4, 2)   \
     X(7, 16, 2, 10, 4, 1)   \
