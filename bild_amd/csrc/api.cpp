@@ -123,6 +123,7 @@ struct bild_trajset {
     std::vector<TrajDesc> descs; // host copy; .x are device pointers
     int dstar_max = 1;
     int Tmax = 0;
+    bool all_valid = true;
     int device = -1;
     double *d_x = nullptr; // all trajectories, each followed by one padding row, then kZeroPad zeros
     double *d_zeros = nullptr;
@@ -481,6 +482,7 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
     p.S = m.S;
     p.d = m.d;
     p.has_G = m.has_G ? 1 : 0;
+    p.all_valid = ts.all_valid ? 1 : 0;
     p.trajs = ts.d_descs;
     p.dstar_max = ts.dstar_max;
     p.ntasks = n * ts.dstar_max;
@@ -693,6 +695,7 @@ int bild_trajset_create(const bild_model *m, int n_traj, const int32_t *T, const
             nvalid += valid;
         }
         td.nvalid = nvalid;
+        ts->all_valid = ts->all_valid && nvalid == T[j];
         // np.unique(err, return_inverse=True): sorted unique values (pyx:145)
         double uniq[kDMax];
         int nu = 0;

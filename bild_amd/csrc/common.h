@@ -46,6 +46,7 @@ struct KParams {
     const double *tab;    // table matrices
     int32_t tab_doubles;
     int32_t S, d, has_G;
+    int32_t all_valid; // no trajectory of the set has a missing frame
     const TrajDesc *trajs;
     int64_t ntasks; // n samples * dstar_max
     int32_t dstar_max;

@@ -105,9 +105,13 @@ __device__ __forceinline__ void matvec_to_lds(XPtr X, const Cols<NP, CPL> &in, d
     }
 }
 
-template <int NP, int CPL, int G, int W, int OCC, int MODE, bool HASG>
+// FLAVOR selects what the frame loop has to carry:
+//   0: external force (G != 0) and missing frames   1: missing frames   2: neither (every frame valid)
+template <int NP, int CPL, int G, int W, int OCC, int MODE, int FLAVOR>
 __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
 {
+    constexpr bool HASG = FLAVOR == 0;
+    constexpr bool ALLVALID = FLAVOR == 2;
     constexpr int kThreads = 64 * W;
     constexpr int kWaves = W;
     constexpr int GPW = 64 / G;          // groups (= tasks in flight) per wavefront
@@ -191,8 +195,12 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
                 xv[q] = *px[q];
                 px[q] += xstep[q];
             }
-            probe = *pprobe;
-            pprobe += d;
+            if (!ALLVALID) {
+                probe = *pprobe;
+                pprobe += d;
+            } else {
+                probe = 0.0;
+            }
         };
 
         const int32_t *__restrict__ sst = p.seg_start + r * K1;
@@ -391,7 +399,7 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
                         }
                     }
             }
-            if (!isnan(probe)) update(xv);
+            if (ALLVALID || !isnan(probe)) update(xv);
         };
 
         // ---- frame 0: update on the steady state, no predict (pyx:186-190); frames are
@@ -399,7 +407,7 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
         double xc[CPL], xn[CPL], pc, pn;
         fetch(xc, pc); // frame 0
         fetch(xn, pn); // frame 1 (or the padding row)
-        if (!isnan(pc)) update(xc);
+        if (ALLVALID || !isnan(pc)) update(xc);
         for (int t = 1; t < T; ++t) {
 #pragma unroll
             for (int q = 0; q < CPL; ++q) xc[q] = xn[q];
@@ -449,8 +457,16 @@ int launch_geom(int mode, const KParams &p, int grid, size_t lds, hipStream_t st
     };
     // G != 0 (an external force on the chain) never occurs through the reference's entry points
     // (rouse.Model is built with F = 0, models.py:246): keep it out of the common kernels
-    if (mode == kModal) return p.has_G ? go(logl_kernel<NP, CPL, G, W, OCC, kModal, true>) : go(logl_kernel<NP, CPL, G, W, OCC, kModal, false>);
-    return p.has_G ? go(logl_kernel<NP, CPL, G, W, OCC, kDense, true>) : go(logl_kernel<NP, CPL, G, W, OCC, kDense, false>);
+    // (and trajectories without a single missing frame out of the masked ones)
+    const int flavor = p.has_G ? 0 : (p.all_valid ? 2 : 1);
+    if (mode == kModal) {
+        if (flavor == 0) return go(logl_kernel<NP, CPL, G, W, OCC, kModal, 0>);
+        if (flavor == 1) return go(logl_kernel<NP, CPL, G, W, OCC, kModal, 1>);
+        return go(logl_kernel<NP, CPL, G, W, OCC, kModal, 2>);
+    }
+    if (flavor == 0) return go(logl_kernel<NP, CPL, G, W, OCC, kDense, 0>);
+    if (flavor == 1) return go(logl_kernel<NP, CPL, G, W, OCC, kDense, 1>);
+    return go(logl_kernel<NP, CPL, G, W, OCC, kDense, 2>);
 }
 
 // (id, rows, columns per lane, lanes per group, waves per workgroup, min waves per SIMD);
