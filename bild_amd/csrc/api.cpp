@@ -109,7 +109,8 @@ struct bild_model {
     int NP = 0; // padded row count; the launch geometry is chosen per batch (geometry_for)
     Mat blob_states[2], blob_tab[2];
     // device residency
-    mutable std::mutex mu;
+    mutable std::mutex mu;      // device residency and workspace growth
+    mutable std::mutex call_mu; // host-buffer evaluations share one workspace: one at a time per model
     mutable int device = -1;
     mutable double *d_states[2] = {nullptr, nullptr};
     mutable double *d_tab[2] = {nullptr, nullptr};
@@ -781,6 +782,7 @@ int bild_logl_segments(const bild_model *m, const bild_trajset *ts, int64_t n, i
                 return fail(BILD_ERR_INVALID, "segment starts of sample %lld are decreasing", (long long)r);
         }
     }
+    std::lock_guard<std::mutex> call_lock(m->call_mu);
     const size_t segbytes = (size_t)n * K1 * sizeof(int32_t);
     int32_t *d_start, *d_state, *d_tid = nullptr;
     double *d_out;

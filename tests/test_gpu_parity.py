@@ -90,13 +90,15 @@ def test_sampler_batch_vs_oracle(built_lib, path, S, T, k, miss):
     assert np.max(np.abs(got - want)) < TOL
 
 
-@pytest.mark.parametrize('N', [2, 4, 7, 8, 16, 20, 31, 32])
+@pytest.mark.parametrize('N', [2, 4, 7, 8, 11, 16, 20, 24, 27, 31, 32, 48, 64])
 def test_chain_lengths(built_lib, N):
     import bild_amd
     from oracle import oracle
     rng = np.random.default_rng(N)
     T = 120
     for reduce in (True, False):
+        if not reduce and N > 32:
+            continue            # beyond the compiled envelope without the reduction (checked in test_error_paths)
         model = bild_amd.MultiStateRouse(N, 1, 2, d=2, localization_error=[0.1, 0.2])
         if not reduce:
             from bild_amd import _lib
@@ -182,6 +184,66 @@ def test_error_paths(built_lib):
     with pytest.raises(AssertionError):        # wrong spatial dimension (reference asserts shapes, pyx:165-166)
         model.logL_batch(np.zeros((1, 10), int), bild_amd.Trajectory(np.zeros((10, 3))))
     assert model.logL_batch(np.zeros((0, 10), int), traj).shape == (0,)
+    big = bild_amd.MultiStateRouse(40, 1, 2, d=1, localization_error=0.1)     # 40 modes after NO reduction
+    a = big.arrays()
+    with pytest.raises(_lib.BildAmdError):                                      # outside the compiled envelope: loud
+        _lib.ModelHandle(a['B'], a['G'], a['Sig'], a['M0'], a['C0'], big.measurement, reduce=False)
+
+
+def test_device_pointer_entry_point(built_lib):
+    """ bild_logl_segments_device: torch tensors in HBM, launch on torch's current stream (what bench.py times) """
+    import torch
+    import bild_amd
+    from bild_amd import _lib
+    from bild_amd.profiles import segments_from_st
+    rng = np.random.default_rng(12)
+    T, n, k = 150, 777, 3
+    model = bild_amd.MultiStateRouse(20, 1, 5, d=3, localization_error=[0.1, 0.1, 0.2])   # d* = 2: exercises the reduce kernel
+    traj = model.trajectory_from_loopingprofile(H.random_profile(rng, T, 2, 40), missing_frames=0.1, rng=rng)
+    ss, thetas = H.candidate_profiles(rng, n, k, 2)
+    want = model.logL_st_batch(ss, thetas, traj)                                # host-buffer entry point
+    a, b = segments_from_st(ss, thetas, T)
+    dev = torch.device('cuda', 0)
+    d_a, d_b = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    out = torch.full((n,), float('nan'), dtype=torch.float64, device=dev)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        _lib.logl_segments_device(model.handle(), model.trajset(traj), n, k + 1, d_a.data_ptr(), d_b.data_ptr(), 0,
+                                  out.data_ptr(), stream=stream.cuda_stream)
+    stream.synchronize()
+    assert np.array_equal(out.cpu().numpy(), want)                              # same kernel, same bits
+
+
+def test_large_batch_and_threads(built_lib):
+    """ a batch that wraps the grid-stride loop many times, and concurrent host-side callers on one model """
+    import threading
+    import bild_amd
+    from oracle import oracle
+    rng = np.random.default_rng(21)
+    T, k = 64, 2
+    model = bild_amd.MultiStateRouse(20, 1, 5, d=3, localization_error=0.1)
+    traj = model.trajectory_from_loopingprofile(H.random_profile(rng, T, 2, 20), rng=rng)
+    n = 600_000
+    ss, thetas = H.candidate_profiles(rng, n, k, 2)
+    got = model.logL_st_batch(ss, thetas, traj)
+    pick = rng.choice(n, 200, replace=False)
+    want = oracle.logl_batch(model.arrays(), model.measurement, model.localization_error, traj[:], H.expand(ss[pick], thetas[pick], T))
+    assert np.all(np.isfinite(got)) and np.max(np.abs(got[pick] - want)) < TOL
+    # identical profiles give identical results wherever they sit in the batch
+    assert np.array_equal(model.logL_st_batch(ss[pick], thetas[pick], traj), got[pick])
+
+    results = {}
+
+    def worker(i):
+        sl = slice(i * 1000, (i + 1) * 1000)
+        results[i] = model.logL_st_batch(ss[sl], thetas[sl], traj)
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(6)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    for i in range(6):
+        assert np.array_equal(results[i], got[i * 1000:(i + 1) * 1000])
 
 
 class _OracleRouse:
