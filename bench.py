@@ -114,8 +114,6 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
-    if rank == 0:
-        entry.build()
     n_dev = torch.cuda.device_count()
     if args.backend == 'nccl' and world > n_dev:
         raise SystemExit(f"{world} ranks but {n_dev} GPUs (use --backend gloo to rehearse)")
@@ -126,6 +124,10 @@ def main():
             dist.init_process_group('nccl', device_id=torch.device('cuda', dev_index))
         else:
             dist.init_process_group('gloo')
+    # the native library is built in-tree by rank 0 only (normally a no-op: the .so travels with the repo)
+    if rank == 0:
+        entry.build()
+    if world > 1:
         dist.barrier()
 
     from bild_amd import _lib
