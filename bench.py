@@ -239,6 +239,39 @@ def main():
                 'achieved': dcan / (dkms * 1e-3) / 1e12, 'frac': dcan / (dkms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                 'executed_frac': dexe / (dkms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
             }
+        if not args.no_dense and not args.no_reduce:
+            # the reference's literal algorithm: all N monomers, C <- B C B + Sig every frame
+            # (canonical flop count == executed flop count)
+            a_ = model.arrays()
+            h_full = _lib.ModelHandle(a_['B'], a_['G'], a_['Sig'], a_['M0'], a_['C0'], model.measurement, reduce=False)
+            ts_full = _lib.TrajSetHandle(h_full, [np.asarray(traj[:])], np.asarray(model.localization_error)[None, :])
+            reps = 3
+            _lib.kernel_timing(False)
+            for _ in range(1):
+                _lib.logl_segments_device(h_full, ts_full, n, k + 1, d_start.data_ptr(), d_state.data_ptr(), 0,
+                                          d_out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream, path='dense')
+            _lib.kernel_timing(True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                _lib.logl_segments_device(h_full, ts_full, n, k + 1, d_start.data_ptr(), d_state.data_ptr(), 0,
+                                          d_out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream, path='dense')
+            torch.cuda.synchronize()
+            cdt = time.perf_counter() - t0
+            _lib.kernel_timing(False)
+            ckms, claunches, cname = _lib.kernel_timing_read()
+            ckms /= max(claunches, 1)
+            ccan, cexe = _lib.flop_count(h_full, ts_full, n, path='dense')
+            full_out = d_out.cpu().numpy().copy()
+            result['canonical_path'] = {
+                'what': 'dense path without reduction: the reference recursion itself on all %d monomers' % h_full.query(_lib.Q_N),
+                'value': n * reps / cdt, 'unit': 'evals/s', 'kernel': cname, 'kernel_ms': ckms,
+                'achieved': ccan / (ckms * 1e-3) / 1e12, 'unit_achieved': 'TFLOP/s fp64',
+                'frac': ccan / (ckms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+            }
+            step(args.path)
+            torch.cuda.synchronize()
+            result['canonical_path']['max_abs_diff_vs_default_path'] = float(np.max(np.abs(full_out - d_out.cpu().numpy())))
         if args.host_buffers:
             # PCIe-inclusive rate of the synchronous host entry point (never `value`)
             for _ in range(2):
