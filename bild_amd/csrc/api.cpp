@@ -426,11 +426,10 @@ int analyse(bild_model &m)
 
 size_t lds_bytes(const bild_model &m, const Geometry &geom, int mode)
 {
-    // dense: propagator tables + per-group product images; modal: product images only (the
-    // basis-change matrices are read through L2, they are touched only at state switches)
+    // matrix tables (dense: B_s, Sig_s; modal: basis changes R) + per-group product images
     const size_t groups = (size_t)geom.W * (64 / geom.G);
     const size_t image = (size_t)group_image_doubles(geom.NP);
-    return ((mode == kDense ? m.blob_tab[mode].size() : 0) + groups * image) * sizeof(double);
+    return (m.blob_tab[mode].size() + groups * image) * sizeof(double);
 }
 
 int ensure_device(const bild_model &m)

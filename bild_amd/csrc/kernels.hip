@@ -76,11 +76,11 @@ __device__ __forceinline__ void matvec_to_lds(XPtr X, const Cols<NP, CPL> &in, d
     constexpr int R = (CPL == 1) ? 1 : 2;
 #pragma unroll 1
     for (int i = 0; i < NP; i += R) {
-        double a[R][CPL];
+        double a[R][CPL], a2[R][CPL]; // even / odd k: two dependent chains per output instead of one
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
-            for (int q = 0; q < CPL; ++q) a[r][q] = 0.0;
+            for (int q = 0; q < CPL; ++q) a[r][q] = a2[r][q] = 0.0;
 #pragma unroll
         for (int k = 0; k < NP; k += 2) {
             double2 x[R];
@@ -91,9 +91,13 @@ __device__ __forceinline__ void matvec_to_lds(XPtr X, const Cols<NP, CPL> &in, d
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     a[r][q] = fma(x[r].x, in.v[q][k], a[r][q]);
-                    a[r][q] = fma(x[r].y, in.v[q][k + 1], a[r][q]);
+                    a2[r][q] = fma(x[r].y, in.v[q][k + 1], a2[r][q]);
                 }
         }
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) a[r][q] += a2[r][q];
 #pragma unroll
         for (int q = 0; q < CPL; ++q)
             if (store[q]) {
@@ -128,14 +132,15 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
     const int grp = lane / G;
     const int gl = lane - grp * G;
 
-    if (MODE == kDense) { // propagators are needed every frame: keep them in LDS
-        for (int i = tid; i < p.tab_doubles; i += kThreads) smem[i] = p.tab[i];
-        __syncthreads();
-    }
+    // Matrix tables live in LDS for the whole kernel: the dense propagators are needed every frame,
+    // and a modal basis change walks its matrix row by row in a dependent loop -- from L2 that was
+    // ~500 cycles per row, 10 us per switch (measured: +89 % kernel time at k = 20).
+    for (int i = tid; i < p.tab_doubles; i += kThreads) smem[i] = p.tab[i];
+    __syncthreads();
     // per-group scratch: image of X*A, NP + kDMax columns of NP doubles; its first NP doubles
     // double as the all-gather buffer of the update
     if (grp >= GPW) return; // lanes beyond the last whole group (64 % G != 0) idle
-    const int lds_tab = (MODE == kDense) ? p.tab_doubles : 0;
+    const int lds_tab = p.tab_doubles;
     double *const scratch = smem + lds_tab + (size_t)(wv * GPW + grp) * group_image_doubles(NP);
 
     int cidx[CPL];
@@ -353,7 +358,7 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
                 } while (t >= next_start);
                 const int sn = ssv[seg];
                 if (sn != s) {
-                    if (MODE == kModal) sandwich(p.tab + (size_t)(sn * S + s) * MS, [] {});
+                    if (MODE == kModal) sandwich(const_cast<const double *>(smem) + (size_t)(sn * S + s) * MS, [] {});
                     s = sn;
                     load_state(s);
                 }
