@@ -470,7 +470,7 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
     int rc = pick_mode(m, flags, &mode);
     if (rc) return rc;
     Geometry geom;
-    if (!geometry_for(m.NP, n * ts.dstar_max, &geom)) return fail(BILD_ERR_UNSUPPORTED, "no kernel for %d rows", m.NP);
+    if (!geometry_for(m.NP, mode, n * ts.dstar_max, &geom)) return fail(BILD_ERR_UNSUPPORTED, "no kernel for %d rows", m.NP);
     const size_t lds = lds_bytes(m, geom, mode);
     if (lds > 160 * 1024)
         return fail(BILD_ERR_UNSUPPORTED, "model tables need %zu bytes of LDS (> 160 KiB): too many states for chain length %d", lds, m.n);

@@ -64,6 +64,7 @@ struct Geometry {
     int W;          // wavefronts per workgroup
     int OCC;        // wavefronts per SIMD the register allocation is bounded for
     int id;         // index into the compiled-kernel table
+    int modes;      // paths that may pick it automatically: 1 dense, 2 modal
     int tasks_per_wave() const { return 64 / G; }
 };
 
@@ -77,7 +78,7 @@ int launch_reduce_partials(const double *partial, double *out, int64_t n, int ds
 int padded_rows(int n_rows);
 // launch geometry for `ntasks` recursions of a chain padded to NP rows (several are compiled per NP:
 // few tasks per wave for small batches, many for throughput); env BILD_GEOM=<id> overrides.
-bool geometry_for(int NP, int64_t ntasks, Geometry *g);
+bool geometry_for(int NP, int mode, int64_t ntasks, Geometry *g);
 const char *kernel_name(const Geometry &g, int mode);
 
 } // namespace bild

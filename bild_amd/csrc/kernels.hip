@@ -486,28 +486,33 @@ int launch_geom(int mode, const KParams &p, int grid, size_t lds, hipStream_t st
 //    wave at the same instruction count (13 of 14 column slots used).
 //    One column per lane (1, 13) at three waves per SIMD has the shortest frame latency
 //    (0.28 us vs 0.46 us per frame for a lone wave) and wins up to ~12k tasks; (2, 7) beyond.
-//  * NP = 16 / 20: forcing two waves per SIMD (OCC = 2, with or without the predict-factor
-//    table) spills inside the frame loop and is 4-6x slower; 2 columns per lane wins for
-//    batches up to ~1000 waves, 3 columns per lane beyond.
-#define BILD_GEOMETRIES(X)  \
-    X(0, 4, 2, 4, 4, 2)     \
-    X(1, 8, 3, 4, 4, 2)     \
-    X(2, 10, 1, 13, 4, 3)   \
-    X(3, 10, 2, 7, 4, 2)    \
-    X(4, 12, 1, 15, 4, 2)   \
-    X(5, 12, 2, 8, 4, 2)    \
-    X(6, 16, 1, 19, 4, 2)   \
-    X(7, 16, 2, 10, 4, 1)   \
-    X(8, 16, 3, 7, 4, 1)    \
-    X(9, 20, 1, 23, 4, 2)   \
-    X(10, 20, 2, 12, 4, 1)  \
-    X(11, 20, 3, 8, 4, 1)   \
-    X(12, 24, 4, 8, 2, 1)   \
-    X(13, 28, 4, 8, 2, 1)   \
-    X(14, 32, 3, 16, 2, 1)
+//  * NP = 16 / 20: one column per lane at two waves per SIMD beats 2 and 3 columns per lane (one
+//    wave per SIMD) at every batch size from 3 000 to 160 000 tasks; forcing two waves per SIMD
+//    onto the multi-column geometries spills inside the frame loop (4-6x slower).
+//  * NP >= 24: the multi-column geometries spill in the frame loop even at one wave per SIMD
+//    (10-20x slower); one column per lane (1-2 tasks per wave) does not.
+// last field: which paths may select the geometry automatically (1 = dense, 2 = modal, 3 = both).
+// The dense recursion is FMA-bound with one LDS operand feeding 2*CPL FMAs, so it wants several
+// columns per lane where the modal one wants a single column.
+#define BILD_GEOMETRIES(X)     \
+    X(0, 4, 1, 7, 4, 3, 3)     \
+    X(1, 4, 2, 4, 4, 2, 3)     \
+    X(2, 8, 1, 11, 4, 3, 3)    \
+    X(3, 10, 1, 13, 4, 3, 3)   \
+    X(4, 10, 2, 7, 4, 2, 3)    \
+    X(5, 12, 1, 15, 4, 2, 3)   \
+    X(6, 12, 2, 8, 4, 2, 3)    \
+    X(7, 16, 1, 19, 4, 2, 2)   \
+    X(8, 16, 3, 7, 4, 1, 1)    \
+    X(9, 20, 1, 23, 4, 2, 2)   \
+    X(10, 20, 2, 12, 4, 1, 1)  \
+    X(11, 20, 3, 8, 4, 1, 1)   \
+    X(12, 24, 1, 27, 4, 1, 3)  \
+    X(13, 28, 1, 31, 4, 1, 3)  \
+    X(14, 32, 1, 35, 4, 1, 3)
 
 constexpr Geometry kGeoms[] = {
-#define X(ID, NP, CPL, G, W, OCC) {NP, CPL, G, W, OCC, ID},
+#define X(ID, NP, CPL, G, W, OCC, MODES) {NP, CPL, G, W, OCC, ID, MODES},
     BILD_GEOMETRIES(X)
 #undef X
 };
@@ -523,7 +528,7 @@ int padded_rows(int n_rows)
     return 0;
 }
 
-bool geometry_for(int NP, int64_t ntasks, Geometry *g)
+bool geometry_for(int NP, int mode, int64_t ntasks, Geometry *g)
 {
     if (const char *ov = getenv("BILD_GEOM")) {
         const int id = atoi(ov);
@@ -533,13 +538,24 @@ bool geometry_for(int NP, int64_t ntasks, Geometry *g)
         }
     }
     // candidates are listed by increasing tasks per wave: take the first one whose waves are all
-    // resident at once (256 CUs x 4 SIMDs x OCC waves), else the densest
+    // resident at once (256 CUs x 4 SIMDs x OCC waves); if none is, the one with the smallest
+    // (rounds of resident waves) x (cost of a frame ~ CPL + c0), c0 = per-frame overhead in units of
+    // one column's work (dense: FMA-bound, ~0; modal: ~2)
     const Geometry *best = nullptr;
+    int64_t best_cost = 0;
     for (const Geometry &c : kGeoms) {
-        if (c.NP != NP || c.id >= kFirstExperimental) continue;
-        best = &c;
+        if (c.NP != NP || c.id >= kFirstExperimental || !(c.modes & (mode == kDense ? 1 : 2))) continue;
         const int64_t waves = (ntasks + c.tasks_per_wave() - 1) / c.tasks_per_wave();
-        if (waves <= 1024 * (int64_t)c.OCC) break;
+        const int64_t slots = 1024 * (int64_t)c.OCC;
+        if (waves <= slots) {
+            best = &c;
+            break;
+        }
+        const int64_t cost = ((waves + slots - 1) / slots) * (c.CPL + (mode == kDense ? 0 : 2));
+        if (!best || cost < best_cost) {
+            best = &c;
+            best_cost = cost;
+        }
     }
     if (!best) return false;
     *g = *best;
@@ -552,7 +568,7 @@ int launch_logl(const Geometry &g, int mode, const KParams &p, int grid, size_t 
 {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     switch (g.id) {
-#define X(ID, NP, CPL, G, W, OCC) \
+#define X(ID, NP, CPL, G, W, OCC, MODES) \
     case ID: return launch_geom<NP, CPL, G, W, OCC>(mode, p, grid, lds, st);
         BILD_GEOMETRIES(X)
 #undef X
