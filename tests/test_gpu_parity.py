@@ -313,3 +313,68 @@ def test_sample_many_and_postproc_gpu(built_lib):
         except postproc.BoundaryEliminationError:
             with pytest.raises(postproc.BoundaryEliminationError):
                 postproc.optimize_boundary(prof, traj, oracle_model)
+
+
+def _spot_check(model, trajs, seg_start, seg_state, tid, got, rng, n_check, Ts):
+    from oracle import oracle
+    from bild_amd.profiles import states_from_segments
+    pick = rng.choice(len(got), n_check, replace=False)
+    worst = 0.0
+    for i in pick:
+        j = int(tid[i])
+        st = states_from_segments(seg_start[i:i + 1], seg_state[i:i + 1], Ts[j])
+        want = oracle.logl(model.arrays(), model.measurement, model._get_noise(trajs[j]), trajs[j][:], st[0])
+        worst = max(worst, abs(got[i] - want))
+    return worst
+
+
+def test_baseline_config3_shape(built_lib):
+    """
+    BASELINE configs[2] per-GPU share: 32 trajectories x 1000 samples, T = 1000, 2-state, one launch over the
+    device-resident trajectory set (the full config is 256 trajectories over 8 GPUs, sharded by trajectory).
+    """
+    import bild_amd
+    from bild_amd.profiles import segments_from_st
+    from bild_amd.dist import shard_by_trajectory
+    rng = np.random.default_rng(33)
+    T, n_traj, per, k = 1000, 32, 1000, 4
+    owners = shard_by_trajectory(np.full(256, T), np.full(256, per), 8)
+    assert all(len(o) == n_traj for o in owners)
+    model = bild_amd.MultiStateRouse(20, 1, 5, d=3, localization_error=0.1)
+    trajs = [model.trajectory_from_loopingprofile(H.random_profile(rng, T, 2, 200), rng=rng) for _ in range(n_traj)]
+    ss, thetas = H.candidate_profiles(rng, n_traj * per, k, 2)
+    seg_start, seg_state = segments_from_st(ss, thetas, T)
+    tid = np.repeat(np.arange(n_traj), per).astype(np.int32)
+    got = model.logL_segments(seg_start, seg_state, trajs, tid)
+    assert got.shape == (n_traj * per,) and np.all(np.isfinite(got))
+    assert _spot_check(model, trajs, seg_start, seg_state, tid, got, rng, 48, [T] * n_traj) < TOL
+    # the same samples, shuffled across trajectories: placement in the batch must not matter
+    perm = rng.permutation(len(got))
+    again = model.logL_segments(seg_start[perm], seg_state[perm], trajs, tid[perm])
+    assert np.array_equal(again, got[perm])
+
+
+def test_baseline_config4_shape(built_lib):
+    """
+    BASELINE configs[3]: 3-state model, T = 2000, mixed missing-frame masks (none / iid 10 % / bursty 30 %,
+    frame 0 missing in half of them), several trajectories in one batch.
+    """
+    import bild_amd
+    from bild_amd.profiles import segments_from_st
+    rng = np.random.default_rng(44)
+    T, per, k = 2000, 1250, 5
+    model = bild_amd.MultiStateRouse(20, 1, 5, d=3, looppositions=H.LOOPS[3], localization_error=0.1)
+    trajs = []
+    for j, kind in enumerate(['none', 'iid', 'bursty', 'bursty']):
+        miss = H.missing_mask(rng, T, kind)
+        if j % 2 == 1:
+            miss = np.union1d(miss, [0])
+        trajs.append(model.trajectory_from_loopingprofile(H.random_profile(rng, T, 3, 300), missing_frames=miss, rng=rng))
+    ss, thetas = H.candidate_profiles(rng, len(trajs) * per, k, 3)
+    seg_start, seg_state = segments_from_st(ss, thetas, T)
+    tid = np.repeat(np.arange(len(trajs)), per).astype(np.int32)
+    for path in PATHS:
+        model.path = path
+        got = model.logL_segments(seg_start, seg_state, trajs, tid)
+        assert np.all(np.isfinite(got))
+        assert _spot_check(model, trajs, seg_start, seg_state, tid, got, rng, 24, [T] * len(trajs)) < TOL
