@@ -1,0 +1,56 @@
+"""
+CPU tests of the Rouse matrix builder (bild_amd/rouse.py): internal consistency of the exact
+one-frame propagator with the steady state, and -- only where the third-party `rouse` package is
+importable (it is not in the build container: "Level M" parity is unpinned) -- a direct
+comparison with ``rouse.Model``.
+"""
+import numpy as np
+import pytest
+
+from bild_amd import rouse as own
+
+
+@pytest.mark.parametrize('N,bonds', [(5, None), (20, None), (20, [(0, -1)]), (12, [(1, 7, 2.0)]), (9, [(0, 4), (4, 8)])])
+def test_propagator_and_steady_state_are_consistent(N, bonds):
+    m = own.Model(N, D=0.7, k=3.0, d=3, add_bonds=bonds)
+    m.check_dynamics()
+    B, Sig, C0 = m._dynamics['B'], m._dynamics['Sig'], m._dynamics['C0']
+    assert np.allclose(B, B.T, atol=1e-14) and np.allclose(Sig, Sig.T, atol=1e-14)
+    # the steady state is a fixed point of the covariance propagation on the internal modes ...
+    assert np.allclose(B @ C0 @ B + Sig - C0, np.full_like(C0, (B @ C0 @ B + Sig - C0)[0, 0]), atol=1e-11)
+    # ... and the only non-stationary direction is the free centre-of-mass mode (uniform vector), which
+    # gains 2 D per frame spread over the N monomers
+    drift = B @ C0 @ B + Sig - C0
+    assert np.allclose(drift, 2 * 0.7 / N, atol=1e-11)
+    # uniform vector: eigenvector of B with eigenvalue 1 (all rows of the Laplacian sum to zero)
+    assert np.allclose(B @ np.ones(N), np.ones(N), atol=1e-12)
+    # composition: two frames == one frame of twice the rate constant only if k scales time; check the
+    # semigroup property instead: B(k) B(k) == B(2k)
+    m2 = own.Model(N, D=0.7, k=6.0, d=3, add_bonds=bonds)
+    m2.check_dynamics()
+    assert np.allclose(B @ B, m2._dynamics['B'], atol=1e-12)
+
+
+def test_external_force_shifts_the_mean():
+    m = own.Model(8, D=1, k=2, d=2)
+    m.F[0] = [1.0, -0.5]
+    m.F[-1] = [-1.0, 0.5]
+    m.update_dynamics()
+    M0, _ = m.steady_state()
+    assert np.allclose(m.propagate_M(M0), M0, atol=1e-12)          # fixed point of the mean propagation
+    assert np.abs(M0).max() > 0.1
+
+
+def test_matches_rouse_package_if_installed():
+    rouse = pytest.importorskip('rouse')
+    for N, bonds in [(20, None), (20, [(0, -1)])]:
+        ref = rouse.Model(N, 1., 5., 3, add_bonds=bonds)
+        ref.check_dynamics()
+        mine = own.Model(N, 1., 5., 3, add_bonds=bonds)
+        mine.check_dynamics()
+        for key in ('B', 'G', 'Sig'):
+            assert np.allclose(mine._dynamics[key], ref._dynamics[key], atol=1e-12), key
+        # the steady state may differ in the centre-of-mass convention only: compare on sum(w) = 0 observables
+        w = np.zeros(N)
+        w[0], w[-1] = -1, 1
+        assert abs(w @ mine.steady_state()[1] @ w - w @ ref.steady_state()[1] @ w) < 1e-10
