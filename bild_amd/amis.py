@@ -81,6 +81,17 @@ class Dirichlet:
         out[pole] = np.inf
         return out
 
+    def logpdf_many(self, As, ss):
+        """ log densities of the rows of ``ss`` under each concentration vector of ``As`` (P, k+1) -> (P, N) """
+        As = np.asarray(As, dtype=np.float64)
+        ss = np.atleast_2d(np.asarray(ss, dtype=np.float64))
+        log_norm = gammaln(np.sum(As, axis=1)) - np.sum(gammaln(As), axis=1)            # (P,)
+        with np.errstate(divide='ignore', invalid='ignore'):
+            out = log_norm[:, None] + np.sum(xlogy(As[:, None, :] - 1., ss[None, :, :]), axis=2)
+        pole = np.any((ss[None, :, :] == 0) & (As[:, None, :] < 1), axis=2)
+        out[pole] = np.inf
+        return out
+
     def estimate(self, ss, log_weights):
         """
         Weighted method of moments (bild/amis.py:110-151): mean m, variance v per component,
@@ -136,23 +147,54 @@ class CFC:
         return thetas
 
     def logpmf(self, logp, thetas):
-        """ log probability of each trace (bild/amis.py:258-282) """
+        """
+        log probability of each trace (bild/amis.py:258-282).
+
+        The normaliser of slot i >= 1 depends only on (i, theta[i-1]): it is computed once per pair
+        -- an (n, k) table -- and gathered, instead of one masked logsumexp per sample as in the
+        reference; the values are the same.  (With the GPU likelihood this bookkeeping, re-run for
+        every earlier sample at every AMIS step, is what an AMIS step costs.)
+        """
         thetas = np.asarray(thetas)
         N, k1 = thetas.shape
-        picked = logp[thetas, np.arange(k1)[None, :]]                      # (N, k+1)
-        #  normaliser of slot i >= 1: weights of the successors of theta[i-1]
-        log_norm = _masked_logsumexp(logp.T[None, 1:, :], self.transitions[thetas[:, :-1]], axis=-1)  # (N, k)
+        picked = logp[thetas, np.arange(k1)[None, :]]                                   # (N, k+1)
+        # norm_table[prev, i-1] = logsumexp of logp[:, i] over the successors of state prev
+        norm_table = _masked_logsumexp(logp.T[None, 1:, :], self.transitions[:, None, :], axis=-1)   # (n, k)
+        log_norm = norm_table[thetas[:, :-1], np.arange(k1 - 1)[None, :]]               # (N, k)
         with np.errstate(under='ignore'):
             log_norm0 = logsumexp(logp[:, 0])
         return np.sum(picked, axis=1) - np.sum(log_norm, axis=1) - log_norm0
 
+    def logpmf_many(self, logps, thetas):
+        """ log probabilities of the traces under each weight matrix of ``logps`` (P, n, k+1) -> (P, N) """
+        logps = np.asarray(logps, dtype=float)
+        thetas = np.asarray(thetas)
+        N, k1 = thetas.shape
+        slots = np.arange(k1)[None, :]
+        picked = logps[:, thetas, slots]                                                 # (P, N, k+1)
+        norm_table = _masked_logsumexp(np.swapaxes(logps, 1, 2)[:, None, 1:, :], self.transitions[None, :, None, :],
+                                       axis=-1)                                          # (P, n, k)
+        log_norm = norm_table[:, thetas[:, :-1], np.arange(k1 - 1)[None, :]]             # (P, N, k)
+        with np.errstate(under='ignore'):
+            log_norm0 = logsumexp(logps[:, :, 0], axis=1)                                # (P,)
+        return np.sum(picked, axis=2) - np.sum(log_norm, axis=2) - log_norm0[:, None]
+
     # -- estimation -------------------------------------------------------------------
     def estimate(self, thetas, log_weights):
-        """ weighted marginals per slot -> weight parameters (bild/amis.py:284-307) """
+        """
+        weighted marginals per slot -> weight parameters (bild/amis.py:284-307).  The marginals are
+        accumulated with one weighted histogram per slot (shifted by the largest log-weight) instead of
+        a masked logsumexp over an (n, N, k+1) indicator array.
+        """
         thetas = np.asarray(thetas)
-        hit = thetas[None, :, :] == np.arange(self.n)[:, None, None]       # (n, N, k+1)
-        log_marginals = _masked_logsumexp(np.asarray(log_weights)[None, :, None], hit, axis=1)
+        log_weights = np.asarray(log_weights, dtype=float)
+        top = np.max(log_weights)
         with np.errstate(under='ignore'):
+            w = np.exp(log_weights - top) if np.isfinite(top) else np.zeros_like(log_weights)
+        marg = np.stack([np.bincount(thetas[:, i], weights=w, minlength=self.n)[:self.n]
+                         for i in range(thetas.shape[1])], axis=1)                      # (n, k+1)
+        with np.errstate(divide='ignore', under='ignore'):
+            log_marginals = np.log(marg) + top
             log_marginals = log_marginals - logsumexp(log_marginals, axis=0, keepdims=True)
         return self.logp_from_marginals(log_marginals)
 
@@ -380,29 +422,45 @@ class FixedkSampler:
 
         a_cur, logp_cur = self.parameters[-1]
 
-        # the mixture denominator of every earlier sample gains the current proposal
-        for old in self.samples:
-            old['cur_log_proposal'] = self.log_proposal(self.parameters[-1], old['ss'], old['thetas'])
+        # The bookkeeping below is the reference's, evaluated on pooled arrays: one call per quantity
+        # and step instead of one per earlier sample / earlier proposal (with the likelihood on the GPU
+        # this host-side part is what an AMIS step costs).
+        # 1. the mixture denominator of every earlier sample gains the current proposal
+        if self.samples:
+            sizes = np.cumsum([len(old['logLs']) for old in self.samples])[:-1]
+            cur_old = self.log_proposal(self.parameters[-1], self._pool['ss'], self._pool['thetas'])
             with np.errstate(under='ignore'):
-                old['logδs'] = np.logaddexp(old['logδs'], old['cur_log_proposal'])
+                logd_old = np.logaddexp(np.concatenate([old['logδs'] for old in self.samples]), cur_old)
+            for old, c, ld in zip(self.samples, np.split(cur_old, sizes), np.split(logd_old, sizes)):
+                old['cur_log_proposal'] = c
+                old['logδs'] = ld
 
+        # 2. the new sample and its own denominator: all proposals used so far
         new = {
             'ss': self.dirichlet.sample(a_cur, self.N),
             'thetas': self.cfc.sample(logp_cur, self.N),
         }
         new['logLs'] = self.logL(new['ss'], new['thetas'])
-        new['cur_log_proposal'] = self.log_proposal(self.parameters[-1], new['ss'], new['thetas'])
+        per_proposal = (self.dirichlet.logpdf_many([par[0] for par in self.parameters], new['ss'])
+                        + self.cfc.logpmf_many([par[1] for par in self.parameters], new['thetas']))   # (steps, N)
+        new['cur_log_proposal'] = per_proposal[-1]
         with np.errstate(under='ignore'):
-            new['logδs'] = logsumexp([self.log_proposal(par, new['ss'], new['thetas']) for par in self.parameters[:-1]]
-                                     + [new['cur_log_proposal']], axis=0)
+            new['logδs'] = logsumexp(per_proposal, axis=0)
         self.samples.append(new)
+        if len(self.samples) == 1:
+            self._pool = {'ss': new['ss'], 'thetas': new['thetas']}
+        else:
+            self._pool = {'ss': np.concatenate([self._pool['ss'], new['ss']]),
+                          'thetas': np.concatenate([self._pool['thetas'], new['thetas']])}
 
-        # deterministic-mixture weights: L / mean over proposals
+        # 3. deterministic-mixture weights: L / mean over proposals
         log_nprop = np.log(len(self.parameters))
         for smp in self.samples:
             smp['log_weights'] = smp['logLs'] - smp['logδs'] + log_nprop
 
-        pooled = {key: np.concatenate([smp[key] for smp in self.samples], axis=0) for key in self.samples[-1]}
+        pooled = {key: np.concatenate([smp[key] for smp in self.samples], axis=0)
+                  for key in ('logLs', 'logδs', 'log_weights', 'cur_log_proposal')}
+        pooled['ss'], pooled['thetas'] = self._pool['ss'], self._pool['thetas']
 
         # refit, then brake
         new_a = self.dirichlet.estimate(pooled['ss'], pooled['log_weights'])
@@ -459,12 +517,33 @@ class FixedkSampler:
         return self.st2profile(self.samples[j]['ss'][best_in[j]], self.samples[j]['thetas'][best_in[j]])
 
     def log_marginal_posterior(self):
-        """ (n, T) normalised log posterior marginals of the state at each frame (bild/amis.py:945-972) """
+        """
+        (n, T) normalised log posterior marginals of the state at each frame (bild/amis.py:945-972).
+
+        Samples are expanded to frames in vectorised chunks (one pass per interval) and their weights
+        summed per state -- sums of non-negative terms only, like the reference's logsumexp, so that
+        tiny marginals keep their relative accuracy.
+        """
         pooled = {key: np.concatenate([smp[key] for smp in self.samples]) for key in self.samples[-1]}
         log_weights = pooled['log_weights'] if 'log_weights' in pooled else pooled['logLs']
-        all_states = np.stack([self.st2profile(s, t)[:] for s, t in zip(pooled['ss'], pooled['thetas'])])  # (N, T)
+        T = len(self.traj)
         n = self.model.nStates
-        hit = all_states[:, None, :] == np.arange(n)[None, :, None]
-        logpost = _masked_logsumexp(log_weights[:, None, None], hit, axis=0)
+        thetas = np.asarray(pooled['thetas'])
+        k1 = thetas.shape[1]
+        starts = switch_indices(pooled['ss'], T) if k1 > 1 else np.zeros((len(thetas), 0), dtype=np.int32)
+        top = np.max(log_weights)
         with np.errstate(under='ignore'):
+            w = np.exp(log_weights - top)
+        frames = np.arange(T)[None, :]
+        post = np.zeros((n, T))
+        chunk = max(1, (1 << 22) // max(T, 1))
+        for lo in range(0, len(thetas), chunk):
+            hi = min(lo + chunk, len(thetas))
+            states = np.repeat(thetas[lo:hi, :1], T, axis=1)
+            for i in range(1, k1):                                   # later intervals overwrite, as st2profile does
+                states = np.where(frames >= starts[lo:hi, i - 1:i], thetas[lo:hi, i:i + 1], states)
+            for st in range(n):
+                post[st] += w[lo:hi] @ (states == st)
+        with np.errstate(divide='ignore', under='ignore'):
+            logpost = np.log(post) + top
             return logpost - logsumexp(logpost, axis=0)
