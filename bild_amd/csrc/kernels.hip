@@ -7,9 +7,10 @@
 //
 // Mapping to the machine
 // ----------------------
-// * One task runs on a *group* of G lanes of a wavefront (G = 8 for N = 20), 64/G groups
-//   per wave, 4 waves per workgroup.  Recursions are independent, so there is no
-//   inter-workgroup traffic and no grid-level synchronisation.
+// * One task runs on a *group* of G lanes of a wavefront (G = 13 for the default 2-state model,
+//   which reduces to 10 modes: one lane per column of [C | M]), floor(64/G) groups per wave,
+//   4 waves per workgroup.  Recursions are independent, so there is no inter-workgroup
+//   traffic and no grid-level synchronisation.
 // * The filter state is the augmented matrix  A = [ C | M ]  (NP x (NP + d)): covariance
 //   and the d mean vectors.  A is distributed BY COLUMN: lane gl of the group owns columns
 //   gl*CPL .. gl*CPL+CPL-1 in registers (CPL*NP doubles).  With C symmetric,
@@ -26,7 +27,7 @@
 //   two lane-local mat-vecs per column with an in-group transpose through LDS between
 //   them.  Same code path as the modal basis change.
 // * Propagator / basis-change matrices are staged once per workgroup into LDS and read
-//   as group-wide broadcasts (ds_read_b128); one LDS operand feeds CPL FMAs.
+//   as group-wide broadcasts (ds_read_b128); one LDS operand pair feeds 2*CPL FMAs per row.
 // * fp64 throughout (v_fma_f64).  No MFMA: on gfx950 the f64 matrix pipe has the same
 //   peak as the f64 vector pipe and N = 20 does not tile 16x16x4.
 // * sum_t log S_t is accumulated as a running product with exponent extraction
@@ -64,8 +65,8 @@ struct Cols {
 
 // Tg[c][i] = sum_k X[i][k] * in[q][k]  for the own columns c = cidx[q]: the product X * A is
 // streamed column-major into the group's LDS image Tg (NC columns of NP doubles), two rows at
-// a time, so no second register image of A is needed.  X is row-major (LDS for the dense
-// propagators, global/L2 for the modal basis changes); one X operand feeds CPL FMAs.
+// a time, so no second register image of A is needed.  X is row-major in LDS (dense propagator
+// or modal basis change); one X operand pair feeds 2*CPL FMAs.
 template <int NP, int CPL, typename XPtr>
 __device__ __forceinline__ void matvec_to_lds(XPtr X, const Cols<NP, CPL> &in, double *__restrict__ Tg,
                                               const int (&cidx)[CPL], const bool (&store)[CPL])
