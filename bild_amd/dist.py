@@ -65,3 +65,50 @@ def all_gather_logl_ragged(local, sizes, group=None):
     buf = torch.empty(m * world, dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(buf, pad, group=group)
     return torch.cat([buf[r * m:r * m + int(sizes[r])] for r in range(world)])
+
+
+class ShardedModel:
+    """
+    Multi-GPU likelihood for an AMIS loop that runs replicated on every rank (same seed, hence the
+    same proposals everywhere): each rank evaluates its contiguous shard of the batch on its own GPU
+    and ONE all-gather per AMIS step gives every rank the full log-likelihood vector, from which all
+    ranks form identical weights and refit identical proposals (reference bild/amis.py:843-854).
+
+    Wraps any model offering ``logL_st_batch``; everything else is forwarded.  With
+    ``torch.distributed`` not initialised (or world size 1) it is a transparent pass-through.
+    """
+
+    def __init__(self, model, group=None, device=None):
+        self._model = model
+        self._group = group
+        self._device = device  # where to stage the gathered vector: None -> cuda for nccl, cpu for gloo
+        self.transitions = model.transitions
+
+    def __getattr__(self, name):
+        return getattr(self._model, name)
+
+    def _world(self):
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return 1, 0
+        return dist.get_world_size(self._group), dist.get_rank(self._group)
+
+    def logL(self, profile, traj):
+        return self._model.logL(profile, traj)
+
+    def logL_st_batch(self, ss, thetas, traj):
+        world, rank = self._world()
+        if world == 1:
+            return self._model.logL_st_batch(ss, thetas, traj)
+        import torch
+        import torch.distributed as dist
+        n = len(thetas)
+        bounds = [shard_bounds(n, world, r) for r in range(world)]
+        lo, hi = bounds[rank]
+        local = np.asarray(self._model.logL_st_batch(ss[lo:hi], thetas[lo:hi], traj), dtype=np.float64) if hi > lo \
+            else np.empty(0)
+        device = self._device
+        if device is None:
+            device = 'cuda' if dist.get_backend(self._group) == 'nccl' else 'cpu'
+        full = all_gather_logl_ragged(torch.from_numpy(local).to(device), [b - a for a, b in bounds], self._group)
+        return full.cpu().numpy()

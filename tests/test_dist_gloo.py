@@ -76,3 +76,46 @@ def test_shard_by_trajectory_balances_cost():
     assert sorted(np.concatenate(owners).tolist()) == list(range(64))
     load = np.array([np.sum(T[o] * n[o]) for o in owners], dtype=float)
     assert load.max() / load.mean() < 1.05
+
+
+def _amis_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import bild_amd
+    from bild_amd.dist import ShardedModel
+    from amis_cases import _table
+    from test_core import _SegmentTableModel
+    table = _table(7, 2, 40, [11, 29])
+    inner = _SegmentTableModel([table])
+    traj = bild_amd.Trajectory(np.zeros((40, 1)))
+    np.random.seed(123)                     # replicated loop: same seed on every rank
+    sampler = bild_amd.FixedkSampler(traj, ShardedModel(inner), k=2, N=37, max_fcomplete=10)
+    for _ in range(4):
+        sampler.step()
+    ret[rank] = (np.array(sampler.evidences), np.concatenate([s['logLs'] for s in sampler.samples]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_replicated_amis_with_sharded_likelihood_world2():
+    """ the AMIS loop replicated on 2 ranks, each evaluating half of every batch + one all-gather per step """
+    import bild_amd
+    from amis_cases import _table
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from test_core import _SegmentTableModel
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_amis_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+        (ev0, l0), (ev1, l1) = ret[0], ret[1]
+    assert np.array_equal(ev0, ev1) and np.array_equal(l0, l1)          # ranks stay in lockstep
+    # ... and equal to the single-process run
+    table = _table(7, 2, 40, [11, 29])
+    traj = bild_amd.Trajectory(np.zeros((40, 1)))
+    np.random.seed(123)
+    ref = bild_amd.FixedkSampler(traj, _SegmentTableModel([table]), k=2, N=37, max_fcomplete=10)
+    for _ in range(4):
+        ref.step()
+    assert np.array_equal(np.array(ref.evidences), ev0)
+    assert np.array_equal(np.concatenate([s['logLs'] for s in ref.samples]), l0)
