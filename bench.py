@@ -210,6 +210,8 @@ def main():
         'executed_achieved': exe / ksec / 1e12,
         'executed_frac': exe / ksec / 1e12 / FP64_PEAK_TFLOPS,
         'kernel_ms': kernel_ms,
+        'attainable_fma_peak': 51.5,
+        'attainable_note': 'register-resident v_fma_f64 loop measured on MI355X: 51.5 TFLOP/s at >= 2 waves/SIMD, 34.1 at one (profiles/r01_f64_rates.txt)',
         'hbm_algorithmic_GBps': (n * (k + 1) * 8 + n * 8 + T * 3 * 8) / ksec / 1e9,
         'hbm_frac': (n * (k + 1) * 8 + n * 8 + T * 3 * 8) / ksec / 1e9 / HBM_PEAK_GBS,
         'note': ('path=%s runs the recursion in %d of %d modes (invariant-subspace reduction) and, on the modal '
