@@ -163,7 +163,21 @@ class CFC:
         log_norm = norm_table[thetas[:, :-1], np.arange(k1 - 1)[None, :]]               # (N, k)
         with np.errstate(under='ignore'):
             log_norm0 = logsumexp(logp[:, 0])
-        return np.sum(picked, axis=1) - np.sum(log_norm, axis=1) - log_norm0
+        return np.sum(self._slot_terms(picked, log_norm), axis=-1) - log_norm0
+
+    @staticmethod
+    def _slot_terms(picked, log_norm):
+        """
+        per-slot log probabilities ``picked - log_norm`` (slot 0 un-normalised).  A trace through a state
+        of weight exactly zero has probability zero -- also when every successor allowed after its
+        predecessor has weight zero, where the reference's ``-inf - (-inf)`` gives NaN (possible with a
+        2-state model once the weights of a very peaked posterior have underflowed; the NaN then poisons
+        every weight and ends in "Iteration did not converge").
+        """
+        with np.errstate(invalid='ignore'):
+            rest = picked[..., 1:] - log_norm
+        rest = np.where(picked[..., 1:] == -np.inf, -np.inf, rest)
+        return np.concatenate([picked[..., :1], rest], axis=-1)
 
     def logpmf_many(self, logps, thetas):
         """ log probabilities of the traces under each weight matrix of ``logps`` (P, n, k+1) -> (P, N) """
@@ -177,7 +191,7 @@ class CFC:
         log_norm = norm_table[:, thetas[:, :-1], np.arange(k1 - 1)[None, :]]             # (P, N, k)
         with np.errstate(under='ignore'):
             log_norm0 = logsumexp(logps[:, :, 0], axis=1)                                # (P,)
-        return np.sum(picked, axis=2) - np.sum(log_norm, axis=2) - log_norm0[:, None]
+        return np.sum(self._slot_terms(picked, log_norm), axis=-1) - log_norm0[:, None]
 
     # -- estimation -------------------------------------------------------------------
     def estimate(self, thetas, log_weights):

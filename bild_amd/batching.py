@@ -22,6 +22,10 @@ from .profiles import segments_from_st
 _INT32_MAX = np.iinfo(np.int32).max
 
 
+class _Cancelled(Exception):
+    """raised inside a task whose run was abandoned because another task failed"""
+
+
 class _Task:
     def __init__(self, index, traj):
         self.index = index
@@ -66,14 +70,21 @@ class BatchingModel:
         task.go.wait()
         task.go.clear()
         out, task.answer = task.answer, None
+        if isinstance(out, _Cancelled):
+            raise out
         return out
 
 
-def run_batched(trajs, model, loop, **kwargs):
+def run_batched(trajs, model, loop, return_exceptions=False, **kwargs):
     """
     Run ``loop(traj, model, **kwargs)`` (normally `core.sample`) for every trajectory, fusing
     their likelihood batches.  ``model`` must offer ``logL_segments(seg_start, seg_state, trajs,
     traj_id)`` (`models.MultiStateRouse` does).
+
+    An exception inside one loop (the samplers raise e.g. ``RuntimeError`` when a proposal fit does
+    not converge, amis.py:441) is re-raised here after the other loops have been unwound; with
+    ``return_exceptions=True`` it becomes that trajectory's entry of the returned list instead and
+    the other loops run to completion.
     """
     trajs = list(trajs)
     tasks = [_Task(i, t) for i, t in enumerate(trajs)]
@@ -100,7 +111,15 @@ def run_batched(trajs, model, loop, **kwargs):
             task.go.set()
             task.parked.wait()
         failed = [t for t in live if t.error is not None]
-        if failed:
+        if failed and not return_exceptions:
+            for task in live:   # unwind the loops that are parked on a request
+                if not task.done:
+                    task.answer = _Cancelled()
+                    task.parked.clear()
+                    task.go.set()
+                    task.parked.wait()
+            for th in threads:
+                th.join()
             raise failed[0].error
         live = [t for t in live if not t.done]
         if not live:
@@ -126,4 +145,4 @@ def run_batched(trajs, model, loop, **kwargs):
             pos += n
     for th in threads:
         th.join()
-    return [t.result for t in tasks]
+    return [t.result if t.error is None else t.error for t in tasks]

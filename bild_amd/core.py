@@ -118,7 +118,8 @@ def sample_many(trajs, model, **kwargs):
     `sample` for a list of trajectories, run concurrently; the AMIS batches that are pending at
     the same time are evaluated together in one launch per round (see `batching`).
 
-    Returns a list of `SamplingResults`, one per trajectory, in order.
+    Returns a list of `SamplingResults`, one per trajectory, in order.  With ``return_exceptions=True``
+    a trajectory whose loop raised gets the exception object as its entry instead of aborting the rest.
     """
     from .batching import run_batched
     return run_batched(trajs, model, sample, **kwargs)

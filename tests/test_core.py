@@ -162,3 +162,27 @@ def test_sample_many_is_fused_and_deterministic():
             raise FloatingPointError("boom")
     with pytest.raises(FloatingPointError):
         bild_amd.sample_many(trajs, Broken(tables), **kw)
+
+
+def test_run_batched_task_errors():
+    """ a loop that raises: re-raised by default (others unwound), or returned in place """
+    import threading
+    from bild_amd.batching import run_batched
+    tables = [np.zeros((2, 10)) for _ in range(3)]
+    trajs = [bild_amd.Trajectory(np.full((10, 1), float(j))) for j in range(3)]
+    model = _SegmentTableModel(tables)
+
+    def loop(traj, m, rounds=3):
+        total = 0.
+        for r in range(rounds):
+            if int(traj[0, 0]) == 1 and r == 1:
+                raise RuntimeError("Iteration did not converge")
+            total += float(np.sum(m.logL_st_batch(np.array([[0.5, 0.5]]), np.array([[0, 1]]), traj)))
+        return total
+
+    before = threading.active_count()
+    with pytest.raises(RuntimeError, match="did not converge"):
+        run_batched(trajs, model, loop)
+    assert threading.active_count() == before          # nobody is left parked
+    out = run_batched(trajs, model, loop, return_exceptions=True)
+    assert out[0] == 0. and out[2] == 0. and isinstance(out[1], RuntimeError)
