@@ -119,3 +119,47 @@ def test_replicated_amis_with_sharded_likelihood_world2():
         ref.step()
     assert np.array_equal(np.array(ref.evidences), ev0)
     assert np.array_equal(np.concatenate([s['logLs'] for s in ref.samples]), l0)
+
+
+_RCCL_SCRIPT = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import helpers as H, bild_amd
+from bild_amd import _lib, dist as bdist
+from bild_amd.profiles import segments_from_st
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+rng = np.random.default_rng(3)
+model = bild_amd.MultiStateRouse(20, 1, 5, d=3, localization_error=0.1)
+traj = model.trajectory_from_loopingprofile(H.random_profile(rng, 300, 2, 60), rng=rng)
+ss, thetas = H.candidate_profiles(rng, 257, 3, 2)
+a, b = segments_from_st(ss, thetas, 300)
+dev = torch.device("cuda", 0)
+d_a, d_b = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+d_out = torch.empty(257, dtype=torch.float64, device=dev)
+_lib.logl_segments_device(model.handle(), model.trajset(traj), 257, 4, d_a.data_ptr(), d_b.data_ptr(), 0,
+                          d_out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+full = bdist.all_gather_logl(d_out)                       # device tensors through RCCL
+ragged = bdist.all_gather_logl_ragged(d_out, [257])
+host = model.logL_st_batch(ss, thetas, traj)
+sharded = bdist.ShardedModel(model).logL_st_batch(ss, thetas, traj)
+dist.barrier()
+ok = (np.array_equal(full.cpu().numpy(), host) and np.array_equal(ragged.cpu().numpy(), host)
+      and np.array_equal(sharded, host) and np.all(np.isfinite(host)))
+dist.destroy_process_group()
+print("RCCL_OK" if ok else "RCCL_MISMATCH")
+'''
+
+
+@pytest.mark.gpu
+def test_rccl_allgather_of_device_results(built_lib):
+    """
+    The collective of the multi-GPU path on its real backend (nccl = RCCL), world size 1 -- the one-GPU
+    box cannot hold more ranks on RCCL: device-resident kernel results go through `all_gather_logl`
+    unchanged.  Runs in a child process so the process group does not outlive the test.
+    """
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, '-c', _RCCL_SCRIPT, ROOT], env=env, capture_output=True, text=True, timeout=300)
+    assert 'RCCL_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
