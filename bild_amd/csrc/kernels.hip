@@ -28,8 +28,10 @@
 //   them.  Same code path as the modal basis change.
 // * Propagator / basis-change matrices are staged once per workgroup into LDS and read
 //   as group-wide broadcasts (ds_read_b128); one LDS operand pair feeds 2*CPL FMAs per row.
-// * fp64 throughout (v_fma_f64).  No MFMA: on gfx950 the f64 matrix pipe has the same
-//   peak as the f64 vector pipe and N = 20 does not tile 16x16x4.
+// * fp64 throughout (v_fma_f64).  On gfx950 the f64 matrix pipe has the same peak as -- and, measured,
+//   shares its FMA throughput with -- the f64 vector pipe, and the modal predict is elementwise, so
+//   there is no GEMM to move there; the one use tried (the cross-lane sum S = s2 + w.(Cw) as two
+//   v_mfma_f64_4x4x4_4b, "block layout" below) gains 2-5 % and is kept as an opt-in geometry.
 // * sum_t log S_t is accumulated as a running product with exponent extraction
 //   (frexp) and one log per task, instead of one log per frame.
 #include <hip/hip_runtime.h>
@@ -52,6 +54,17 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Sum of one value per lane over the 16 lanes {4b + c + 16k : c, k < 4} that share lane bits 2-3
+// ("block" b of v_mfma_f64_4x4x4_4b: operands are laid out as lane = row-or-column + 4*block + 16*k,
+// measured with tools/probe/mfma_blocksum.hip), plus `add`; every lane of the block gets the result.
+// First product: rows of A summed over k against B = 1; second: the four row sums summed again.
+// Two issue slots on the matrix pipe instead of a chain of NP FMAs on the vector pipe.
+__device__ __forceinline__ double block_sum16(double v, double add)
+{
+    const double rows = __builtin_amdgcn_mfma_f64_4x4x4f64(v, 1.0, 0.0, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f64_4x4x4f64(rows, 1.0, add, 0, 0, 0);
 }
 
 // log() is needed once per task; out of line, so that its polynomial constants are not hoisted
@@ -120,6 +133,9 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
     constexpr int kThreads = 64 * W;
     constexpr int kWaves = W;
     constexpr int GPW = 64 / G;          // groups (= tasks in flight) per wavefront
+    // block layout: a group is one 16-lane block of the f64 4x4x4 matrix instruction (lanes that share
+    // bits 2-3), so that S = s2 + w.(Cw) is a block sum on the matrix pipe
+    constexpr bool BLK = (G == 16 && CPL == 1);
     constexpr int MS = table_stride(NP); // LDS matrix stride
     constexpr int SB = StateBlock::size(NP);
     static_assert(NP % 2 == 0, "rows are read in pairs");
@@ -130,8 +146,8 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = tid >> 6;
-    const int grp = lane / G;
-    const int gl = lane - grp * G;
+    const int grp = BLK ? ((lane >> 2) & 3) : lane / G;
+    const int gl = BLK ? ((lane & 3) | ((lane >> 4) << 2)) : lane - grp * G;
 
     // Matrix tables live in LDS for the whole kernel: the dense propagators are needed every frame,
     // and a modal basis change walks its matrix row by row in a dependent loop -- from L2 that was
@@ -222,10 +238,12 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
         // (row i == column c of column slot q = i % CPL) and 0 elsewhere.  Rebuilt at switches.
         Cols<NP, CPL> L;
         double sgd[NP];
+        double wown = 0.0; // block layout: w_c of the own covariance column, 0 for the other lanes
         auto load_state = [&](int st) {
             const double *__restrict__ sb = p.states + (size_t)st * SB;
 #pragma unroll
             for (int i = 0; i < NP; ++i) wq[i] = sb[StateBlock::wq(NP) + i];
+            if (BLK) wown = isC[0] ? sb[StateBlock::wq(NP) + cidx[0]] : 0.0;
             if (MODE == kModal) {
                 double mu[CPL], sgc[CPL];
 #pragma unroll
@@ -291,13 +309,18 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
                 cw[i + 1] = t2.y;
             }
             wave_lds_fence();
-            double sa = s2, sb2 = 0.0;
+            double Sv;
+            if (BLK) {
+                Sv = block_sum16(wown * ev[0], s2);
+            } else {
+                double sa = s2, sb2 = 0.0;
 #pragma unroll
-            for (int i = 0; i < NP; i += 2) {
-                sa = fma(wq[i], cw[i], sa);
-                sb2 = fma(wq[i + 1], cw[i + 1], sb2);
+                for (int i = 0; i < NP; i += 2) {
+                    sa = fma(wq[i], cw[i], sa);
+                    sb2 = fma(wq[i + 1], cw[i + 1], sb2);
+                }
+                Sv = sa + sb2;
             }
-            const double Sv = sa + sb2;
             // 1/S: hardware reciprocal seed + two Newton steps (full double precision for the
             // normal, positive S a covariance produces; NaN/Inf/0 propagate as such)
             double Sinv = __builtin_amdgcn_rcp(Sv);
@@ -306,7 +329,7 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
 #pragma unroll
             for (int q = 0; q < CPL; ++q) {
                 const double coef = ev[q] * Sinv; // K_c * S for a covariance column, -nu/S for a mean column
-                accq[q] = fma(ev[q] * ev[q], Sinv, accq[q]);
+                accq[q] = fma(ev[q], coef, accq[q]); // e^2 / S
 #pragma unroll
                 for (int i = 0; i < NP; ++i) col.v[q][i] = fma(-coef, cw[i], col.v[q][i]);
             }
@@ -492,6 +515,12 @@ int launch_geom(int mode, const KParams &p, int grid, size_t lds, hipStream_t st
 //    onto the multi-column geometries spills inside the frame loop (4-6x slower).
 //  * NP >= 24: the multi-column geometries spill in the frame loop even at one wave per SIMD
 //    (10-20x slower); one column per lane (1-2 tasks per wave) does not.
+//  * NP = 10 / 12, one column per lane, G = 16 (ids 15 / 16, only through BILD_GEOM): the block layout -- a
+//    task is one 16-lane block of the f64 4x4x4 matrix instruction and S comes from block_sum16.  2-5 %
+//    faster than the packed (1, 13) / (1, 15) at every batch size, 7 % with missing frames: the f64 matrix
+//    and vector pipes share their FMA throughput, so only the redundancy of the per-lane S chain is saved.
+//    Not selected automatically: its S is summed in another order, and with it the results of one profile
+//    would differ in the last bits between batch sizes (all other geometries of an NP agree bit for bit).
 // last field: which paths may select the geometry automatically (1 = dense, 2 = modal, 3 = both).
 // The dense recursion is FMA-bound with one LDS operand feeding 2*CPL FMAs, so it wants several
 // columns per lane where the modal one wants a single column.
@@ -510,7 +539,9 @@ int launch_geom(int mode, const KParams &p, int grid, size_t lds, hipStream_t st
     X(11, 20, 3, 8, 4, 1, 1)   \
     X(12, 24, 1, 27, 4, 1, 3)  \
     X(13, 28, 1, 31, 4, 1, 3)  \
-    X(14, 32, 1, 35, 4, 1, 3)
+    X(14, 32, 1, 35, 4, 1, 3)  \
+    X(15, 10, 1, 16, 4, 3, 2)  \
+    X(16, 12, 1, 16, 4, 2, 2)
 
 constexpr Geometry kGeoms[] = {
 #define X(ID, NP, CPL, G, W, OCC, MODES) {NP, CPL, G, W, OCC, ID, MODES},
