@@ -20,8 +20,7 @@ import itertools
 import math
 
 import numpy as np
-from scipy import stats
-from scipy.special import gammaln, logsumexp, xlogy
+from scipy.special import gammaln, xlogy
 
 from .profiles import Loopingprofile, switch_indices
 
@@ -29,10 +28,27 @@ from .profiles import Loopingprofile, switch_indices
 # ----------------------------------------------------------------------------------------
 # helpers
 # ----------------------------------------------------------------------------------------
+def logsumexp(a, axis=None, keepdims=False, mask=None):
+    """
+    log(sum(exp(a))) over ``axis`` (over the entries selected by ``mask``, if given), shifted by the largest
+    entry; an empty or all ``-inf`` selection gives ``-inf``.  (scipy.special.logsumexp computes the same;
+    its argument handling costs more than the arithmetic on the small arrays of an AMIS step.)
+    """
+    a = np.asarray(a, dtype=np.float64)
+    if mask is not None:
+        a = np.where(mask, a, -np.inf)
+    top = np.max(a, axis=axis, keepdims=True)
+    top = np.where(np.isfinite(top), top, 0.)
+    with np.errstate(under='ignore', divide='ignore'):
+        out = np.log(np.sum(np.exp(a - top), axis=axis, keepdims=True)) + top
+    if keepdims:
+        return out
+    return out.reshape(())[()] if axis is None else np.squeeze(out, axis=axis)
+
+
 def _masked_logsumexp(logx, mask, axis):
     """ log(sum(exp(logx) * mask)) without warnings for empty selections (-> -inf) """
-    with np.errstate(under='ignore', divide='ignore'):
-        return logsumexp(logx, b=mask, axis=axis)
+    return logsumexp(logx, axis=axis, mask=mask)
 
 
 def _int_matrix_power(T, p):
@@ -63,46 +79,73 @@ class Dirichlet:
 
     def sample(self, a, N=1):
         """ (N, k+1) draws (bild/amis.py:66-81) """
-        return stats.dirichlet(a).rvs(N)
+        return np.random.dirichlet(np.asarray(a, dtype=np.float64), size=N)   # the call scipy.stats.dirichlet.rvs makes
 
-    def logpdf(self, a, ss):
+    def logpdf(self, a, ss, log_ss=None):
         """
         log density at the rows of ``ss`` (bild/amis.py:83-108).
 
         A sample with ``s_i == 0`` where ``a_i < 1`` sits on a pole of the density: ``+inf``
         (pinned by reference tests/test_amis.py:51-54).
+
+        ``log_ss`` (see `log_samples`) lets a caller that evaluates many parameter vectors on the same
+        samples pay for the logarithms once: the sum over components becomes a matrix-vector product.
         """
-        a = np.asarray(a, dtype=np.float64)
-        ss = np.atleast_2d(np.asarray(ss, dtype=np.float64))
-        log_norm = gammaln(np.sum(a)) - np.sum(gammaln(a))
-        with np.errstate(divide='ignore', invalid='ignore'):
-            out = log_norm + np.sum(xlogy(a - 1., ss), axis=1)
-        pole = np.any((ss == 0) & (a[None, :] < 1), axis=1)
-        out[pole] = np.inf
-        return out
+        return self.logpdf_many(np.asarray(a, dtype=np.float64)[None, :], ss, log_ss)[0]
 
-    def logpdf_many(self, As, ss):
+    @staticmethod
+    def log_samples(ss):
+        """
+        (log(ss) transposed to (k+1, N) with zeros where ss == 0, indices of the rows of ``ss`` that contain
+        a zero): what `logpdf(_many)` needs of the samples, for callers that evaluate them repeatedly
+        """
+        ss = np.atleast_2d(np.asarray(ss, dtype=np.float64))
+        zero = ss == 0
+        with np.errstate(divide='ignore'):
+            logs = np.log(ss.T)     # a copy in (k+1, N) order: sums over samples run along contiguous rows
+        if np.any(zero):
+            logs[zero.T] = 0.
+        return logs, np.nonzero(np.any(zero, axis=1))[0]
+
+    def logpdf_many(self, As, ss, log_ss=None):
         """ log densities of the rows of ``ss`` under each concentration vector of ``As`` (P, k+1) -> (P, N) """
-        As = np.asarray(As, dtype=np.float64)
-        ss = np.atleast_2d(np.asarray(ss, dtype=np.float64))
+        As = np.atleast_2d(np.asarray(As, dtype=np.float64))
         log_norm = gammaln(np.sum(As, axis=1)) - np.sum(gammaln(As), axis=1)            # (P,)
-        with np.errstate(divide='ignore', invalid='ignore'):
-            out = log_norm[:, None] + np.sum(xlogy(As[:, None, :] - 1., ss[None, :, :]), axis=2)
-        pole = np.any((ss[None, :, :] == 0) & (As[:, None, :] < 1), axis=2)
-        out[pole] = np.inf
+        logs, zero_rows = self.log_samples(ss) if log_ss is None else log_ss
+        # einsum, not BLAS: single-threaded and summed in a fixed order (runs are reproducible bit for bit)
+        out = np.einsum('pj,jn->pn', As - 1., logs) + log_norm[:, None]
+        if len(zero_rows):   # x log(0): 0 for x = 0, -+inf else; poles of the density are +inf
+            sz = np.atleast_2d(np.asarray(ss, dtype=np.float64))[zero_rows]
+            with np.errstate(divide='ignore', invalid='ignore'):
+                oz = log_norm[:, None] + np.sum(xlogy(As[:, None, :] - 1., sz[None, :, :]), axis=2)
+            oz[np.any((sz[None, :, :] == 0) & (As[:, None, :] < 1), axis=2)] = np.inf
+            out[:, zero_rows] = oz
         return out
 
-    def estimate(self, ss, log_weights):
+    def estimate(self, ss, log_weights, ssT=None):
         """
         Weighted method of moments (bild/amis.py:110-151): mean m, variance v per component,
-        total concentration ``A = mean(m (1-m) / v) - 1``, estimate ``A m``.
+        total concentration ``A = mean(m (1-m) / v) - 1``, estimate ``A m``.  ``ssT``: the samples as a
+        contiguous (k+1, N) array, if the caller keeps one.
+
+        Weights below 1e-100 of the largest are taken as zero: they cannot change a double-precision sum
+        that the largest weight dominates, but their products with small deviations are subnormal, and
+        arithmetic on subnormals is slow enough to dominate an AMIS step over 1e5 pooled samples.
         """
-        ss = np.asarray(ss, dtype=np.float64)
+        if ssT is None:
+            ssT = np.ascontiguousarray(np.asarray(ss, dtype=np.float64).T)
         with np.errstate(under='ignore'):
             w = np.exp(log_weights - np.max(log_weights))
-            w = w / np.sum(w)
-            m = w @ ss
-            v = w @ np.square(ss - m[None, :])
+        w[w < 1e-100] = 0.
+        w = w / np.sum(w)
+        m = np.empty(len(ssT))
+        v = np.empty(len(ssT))
+        for j, col in enumerate(ssT):    # plain reductions over contiguous rows (no BLAS: fixed summation order)
+            m[j] = np.sum(col * w)
+            dev = col - m[j]
+            dev *= dev
+            dev *= w
+            v[j] = np.sum(dev)
         if np.any(v == 0):
             total = 1e10  # degenerate sample: very concentrated but finite, the brake takes over
         else:
@@ -146,52 +189,60 @@ class CFC:
             thetas[:, i] = np.argmax(cdf > np.random.rand(N, 1), axis=1)  # first crossing
         return thetas
 
-    def logpmf(self, logp, thetas):
+    def logpmf(self, logp, thetas, codes=None):
         """
         log probability of each trace (bild/amis.py:258-282).
 
-        The normaliser of slot i >= 1 depends only on (i, theta[i-1]): it is computed once per pair
-        -- an (n, k) table -- and gathered, instead of one masked logsumexp per sample as in the
-        reference; the values are the same.  (With the GPU likelihood this bookkeeping, re-run for
-        every earlier sample at every AMIS step, is what an AMIS step costs.)
+        The probability of slot i >= 1 depends only on (i, theta[i-1], theta[i]): the n*n*k possible
+        terms are tabulated once (`lookup_tables`) and gathered through per-sample integer codes
+        (`trace_codes`), instead of one masked logsumexp per sample as in the reference; the values are
+        the same.  (With the GPU likelihood this bookkeeping, re-run for every earlier sample at every
+        AMIS step, is what an AMIS step costs.)
         """
+        return self.logpmf_many(np.asarray(logp, dtype=float)[None], thetas, codes)[0]
+
+    def trace_codes(self, thetas):
+        """ (theta[0], flat indices (N, k) into the pair table of `lookup_tables`) of the traces """
         thetas = np.asarray(thetas)
-        N, k1 = thetas.shape
-        picked = logp[thetas, np.arange(k1)[None, :]]                                   # (N, k+1)
-        # norm_table[prev, i-1] = logsumexp of logp[:, i] over the successors of state prev
-        norm_table = _masked_logsumexp(logp.T[None, 1:, :], self.transitions[:, None, :], axis=-1)   # (n, k)
-        log_norm = norm_table[thetas[:, :-1], np.arange(k1 - 1)[None, :]]               # (N, k)
-        with np.errstate(under='ignore'):
-            log_norm0 = logsumexp(logp[:, 0])
-        return np.sum(self._slot_terms(picked, log_norm), axis=-1) - log_norm0
+        n = self.n
+        k = thetas.shape[1] - 1
+        pair = (np.arange(k)[None, :] * n + thetas[:, :-1]) * n + thetas[:, 1:]
+        return thetas[:, 0].astype(np.intp), pair.astype(np.intp)
 
-    @staticmethod
-    def _slot_terms(picked, log_norm):
+    def lookup_tables(self, logps):
         """
-        per-slot log probabilities ``picked - log_norm`` (slot 0 un-normalised).  A trace through a state
-        of weight exactly zero has probability zero -- also when every successor allowed after its
-        predecessor has weight zero, where the reference's ``-inf - (-inf)`` gives NaN (possible with a
-        2-state model once the weights of a very peaked posterior have underflowed; the NaN then poisons
-        every weight and ends in "Iteration did not converge").
-        """
-        with np.errstate(invalid='ignore'):
-            rest = picked[..., 1:] - log_norm
-        rest = np.where(picked[..., 1:] == -np.inf, -np.inf, rest)
-        return np.concatenate([picked[..., :1], rest], axis=-1)
+        (P, n) log probabilities of the first state and (P, k*n*n) of every (slot, previous, current)
+        triple under each weight matrix of ``logps`` (P, n, k+1).
 
-    def logpmf_many(self, logps, thetas):
-        """ log probabilities of the traces under each weight matrix of ``logps`` (P, n, k+1) -> (P, N) """
+        A state of weight exactly zero has probability zero -- also when every successor allowed after
+        its predecessor has weight zero, where the reference's ``-inf - (-inf)`` gives NaN (possible with
+        a 2-state model once the weights of a very peaked posterior have underflowed; the NaN then
+        poisons every weight and ends in "Iteration did not converge").
+        """
         logps = np.asarray(logps, dtype=float)
-        thetas = np.asarray(thetas)
-        N, k1 = thetas.shape
-        slots = np.arange(k1)[None, :]
-        picked = logps[:, thetas, slots]                                                 # (P, N, k+1)
-        norm_table = _masked_logsumexp(np.swapaxes(logps, 1, 2)[:, None, 1:, :], self.transitions[None, :, None, :],
-                                       axis=-1)                                          # (P, n, k)
-        log_norm = norm_table[:, thetas[:, :-1], np.arange(k1 - 1)[None, :]]             # (P, N, k)
+        P, n, k1 = logps.shape
         with np.errstate(under='ignore'):
-            log_norm0 = logsumexp(logps[:, :, 0], axis=1)                                # (P,)
-        return np.sum(self._slot_terms(picked, log_norm), axis=-1) - log_norm0[:, None]
+            head = logps[:, :, 0] - logsumexp(logps[:, :, 0], axis=1, keepdims=True)       # (P, n)
+        # norm[p, i-1, prev] = logsumexp of logps[p, :, i] over the successors of state prev
+        by_slot = np.swapaxes(logps, 1, 2)[:, 1:, :]                                        # (P, k, n) current state last
+        norm = _masked_logsumexp(by_slot[:, :, None, :], self.transitions[None, None, :, :], axis=-1)   # (P, k, prev)
+        with np.errstate(invalid='ignore'):
+            pair = by_slot[:, :, None, :] - norm[:, :, :, None]                             # (P, k, prev, cur)
+        pair = np.where(by_slot[:, :, None, :] == -np.inf, -np.inf, pair)
+        return head, pair.reshape(P, -1)
+
+    def logpmf_many(self, logps, thetas, codes=None, tables=None):
+        """
+        log probabilities of the traces under each weight matrix of ``logps`` (P, n, k+1) -> (P, N);
+        ``codes`` = `trace_codes` of the traces and ``tables`` = `lookup_tables` of the matrices, if the
+        caller keeps them.
+        """
+        first, pair = self.trace_codes(thetas) if codes is None else codes
+        head, table = self.lookup_tables(logps) if tables is None else tables
+        out = head[:, first]
+        if pair.shape[1]:
+            out = out + np.sum(table[:, pair], axis=-1)
+        return out
 
     # -- estimation -------------------------------------------------------------------
     def estimate(self, thetas, log_weights):
@@ -303,6 +354,39 @@ class CFC:
 # ----------------------------------------------------------------------------------------
 # the sampler
 # ----------------------------------------------------------------------------------------
+class _SampleList:
+    """
+    ``FixedkSampler.samples`` as the reference presents it -- one dict per AMIS step with the arrays
+    'ss', 'thetas', 'logLs' [, 'logδs', 'log_weights', 'cur_log_proposal'] -- as views of the sampler's
+    pooled arrays, materialised on access (a step itself never walks the list).
+    """
+
+    def __init__(self, sampler):
+        self._s = sampler
+
+    def __len__(self):
+        return len(self._s._sizes)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        n = len(self)
+        if i < 0:
+            i += n
+        if not 0 <= i < n:
+            raise IndexError("sample index out of range")
+        s = self._s
+        lo = int(sum(s._sizes[:i]))
+        hi = lo + s._sizes[i]
+        out = {'ss': s._pool['ss'][lo:hi], 'thetas': s._pool['thetas'][lo:hi]}
+        for key, arr in s._arr.items():
+            out[key] = arr[lo:hi]
+        return out
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+
 class FixedkSampler:
     """
     AMIS (Cornuet et al. 2012) for a fixed number of switches ``k``; one `step` draws ``N``
@@ -345,7 +429,17 @@ class FixedkSampler:
         # uniform prior over profiles: k! / N_total (bild/amis.py:654-659)
         self.logprior = float(np.sum(np.log(np.arange(self.k) + 1))) - self.cfc.N_total(self.k, log=True)
 
-        self.samples = []    # dicts: 'ss', 'thetas', 'logLs' [, 'logδs', 'log_weights', 'cur_log_proposal']
+        # All samples drawn so far live in pooled arrays, in drawing order: `_pool` what is fixed at drawing
+        # time ('ss', 'thetas' and derived lookup data), `_arr` what an AMIS step recomputes for every sample
+        # ('logLs', 'logδs', 'cur_log_proposal', 'log_weights'); `_sizes` the number of samples per step.
+        self._sizes = []
+        self._pool = None
+        self._arr = {}
+        self.samples = _SampleList(self)
+        # per proposal: concentration vector and CFC.lookup_tables, stacked
+        self._As = np.empty((0, self.k + 1))
+        self._heads = np.empty((0, self.cfc.n))
+        self._tables = np.empty((0, self.k * self.cfc.n ** 2))
         self.evidences = []  # (logev, dlogev, KL) per step
 
         try:
@@ -412,7 +506,9 @@ class FixedkSampler:
 
         sample = {'ss': ss, 'thetas': thetas}
         sample['logLs'] = self.logL(ss, thetas)
-        self.samples.append(sample)
+        self._pool = {'ss': ss, 'thetas': thetas}
+        self._arr = {'logLs': sample['logLs']}
+        self._sizes = [len(ss)]
 
         # evidence = mean likelihood under the (uniform) prior ensemble; KL(posterior || prior)
         top = np.max(sample['logLs'])
@@ -439,45 +535,60 @@ class FixedkSampler:
         # The bookkeeping below is the reference's, evaluated on pooled arrays: one call per quantity
         # and step instead of one per earlier sample / earlier proposal (with the likelihood on the GPU
         # this host-side part is what an AMIS step costs).
+        # Per-sample quantities that do not change are kept with the pool (logarithms of the intervals,
+        # lookup codes of the traces), per-proposal ones with the proposals (lookup tables).
+        for par in self.parameters[len(self._As):]:
+            head, table = self.cfc.lookup_tables(par[1][None])
+            self._As = np.concatenate([self._As, np.asarray(par[0], dtype=np.float64)[None]])
+            self._heads = np.concatenate([self._heads, head])
+            self._tables = np.concatenate([self._tables, table])
+
+        def log_proposals(which, pool):
+            """ (len(which), N) log densities of the proposals ``which`` at the samples of ``pool`` """
+            return (self.dirichlet.logpdf_many(self._As[which], pool['ss'], pool['log_ss'])
+                    + self.cfc.logpmf_many(None, None, pool['codes'], (self._heads[which], self._tables[which])))
+
+        pool, arr = self._pool, self._arr
         # 1. the mixture denominator of every earlier sample gains the current proposal
-        if self.samples:
-            sizes = np.cumsum([len(old['logLs']) for old in self.samples])[:-1]
-            cur_old = self.log_proposal(self.parameters[-1], self._pool['ss'], self._pool['thetas'])
+        if self._sizes:
+            cur_old = log_proposals(slice(-1, None), pool)[0]
             with np.errstate(under='ignore'):
-                logd_old = np.logaddexp(np.concatenate([old['logδs'] for old in self.samples]), cur_old)
-            for old, c, ld in zip(self.samples, np.split(cur_old, sizes), np.split(logd_old, sizes)):
-                old['cur_log_proposal'] = c
-                old['logδs'] = ld
+                logd_old = np.logaddexp(arr['logδs'], cur_old)
 
         # 2. the new sample and its own denominator: all proposals used so far
-        new = {
-            'ss': self.dirichlet.sample(a_cur, self.N),
-            'thetas': self.cfc.sample(logp_cur, self.N),
-        }
-        new['logLs'] = self.logL(new['ss'], new['thetas'])
-        per_proposal = (self.dirichlet.logpdf_many([par[0] for par in self.parameters], new['ss'])
-                        + self.cfc.logpmf_many([par[1] for par in self.parameters], new['thetas']))   # (steps, N)
-        new['cur_log_proposal'] = per_proposal[-1]
-        with np.errstate(under='ignore'):
-            new['logδs'] = logsumexp(per_proposal, axis=0)
-        self.samples.append(new)
-        if len(self.samples) == 1:
-            self._pool = {'ss': new['ss'], 'thetas': new['thetas']}
+        new_ss = self.dirichlet.sample(a_cur, self.N)
+        new_thetas = self.cfc.sample(logp_cur, self.N)
+        new_logLs = self.logL(new_ss, new_thetas)
+        fresh = {'ss': new_ss, 'thetas': new_thetas, 'ssT': np.ascontiguousarray(new_ss.T),
+                 'log_ss': self.dirichlet.log_samples(new_ss), 'codes': self.cfc.trace_codes(new_thetas)}
+        per_proposal = log_proposals(slice(None), fresh)                                  # (steps, N)
+        new_logd = logsumexp(per_proposal, axis=0)
+        if not self._sizes:
+            self._pool = fresh
+            arr = {'logLs': new_logLs, 'logδs': new_logd, 'cur_log_proposal': per_proposal[-1]}
         else:
-            self._pool = {'ss': np.concatenate([self._pool['ss'], new['ss']]),
-                          'thetas': np.concatenate([self._pool['thetas'], new['thetas']])}
+            n_old = len(pool['ss'])
+            self._pool = {
+                'ss': np.concatenate([pool['ss'], fresh['ss']]),
+                'thetas': np.concatenate([pool['thetas'], fresh['thetas']]),
+                'ssT': np.concatenate([pool['ssT'], fresh['ssT']], axis=1),
+                'log_ss': (np.concatenate([pool['log_ss'][0], fresh['log_ss'][0]], axis=1),
+                           np.concatenate([pool['log_ss'][1], fresh['log_ss'][1] + n_old])),
+                'codes': (np.concatenate([pool['codes'][0], fresh['codes'][0]]),
+                          np.concatenate([pool['codes'][1], fresh['codes'][1]])),
+            }
+            arr = {'logLs': np.concatenate([arr['logLs'], new_logLs]),
+                   'logδs': np.concatenate([logd_old, new_logd]),
+                   'cur_log_proposal': np.concatenate([cur_old, per_proposal[-1]])}
+        self._sizes.append(len(new_ss))
 
         # 3. deterministic-mixture weights: L / mean over proposals
-        log_nprop = np.log(len(self.parameters))
-        for smp in self.samples:
-            smp['log_weights'] = smp['logLs'] - smp['logδs'] + log_nprop
-
-        pooled = {key: np.concatenate([smp[key] for smp in self.samples], axis=0)
-                  for key in ('logLs', 'logδs', 'log_weights', 'cur_log_proposal')}
-        pooled['ss'], pooled['thetas'] = self._pool['ss'], self._pool['thetas']
+        arr['log_weights'] = arr['logLs'] - arr['logδs'] + np.log(len(self.parameters))
+        self._arr = arr
+        pooled = dict(arr, ss=self._pool['ss'], thetas=self._pool['thetas'])
 
         # refit, then brake
-        new_a = self.dirichlet.estimate(pooled['ss'], pooled['log_weights'])
+        new_a = self.dirichlet.estimate(pooled['ss'], pooled['log_weights'], self._pool['ssT'])
         new_logp = self.cfc.estimate(pooled['thetas'], pooled['log_weights'])
 
         limit_c = self.N * self.brakes[0]
@@ -502,9 +613,10 @@ class FixedkSampler:
         top = np.max(pooled['log_weights'])
         with np.errstate(under='ignore'):
             rel = np.exp(pooled['log_weights'] - top)
+        rel[rel < np.finfo(np.float64).tiny] = 0.   # subnormal weights: no effect on the sums, slow arithmetic
         ev = np.mean(rel)
         logev = np.log(ev) + top + self.logprior
-        dlogev = stats.sem(rel) / ev
+        dlogev = np.std(rel, ddof=1) / np.sqrt(len(rel)) / ev      # standard error of the mean
         with np.errstate(under='ignore', invalid='ignore'):
             # zero-weight samples with cur_log_proposal = -inf give nan terms: dropped from the
             # sum but kept in the normalisation (bild/amis.py:883-898)
@@ -512,7 +624,7 @@ class FixedkSampler:
                   - logev + self.logprior)
         self.evidences.append((logev, dlogev, KL))
 
-        if (len(self.samples) + 1) * self.N >= self.max_fev:
+        if (len(self._sizes) + 1) * self.N >= self.max_fev:
             self.exhausted = True
         return True
 
@@ -525,10 +637,8 @@ class FixedkSampler:
 
     def MAP_profile(self):
         """ the sampled profile of highest likelihood (bild/amis.py:928-943) """
-        best_in = [int(np.argmax(smp['logLs'])) for smp in self.samples]
-        best_val = [smp['logLs'][i] for smp, i in zip(self.samples, best_in)]
-        j = int(np.argmax(best_val))
-        return self.st2profile(self.samples[j]['ss'][best_in[j]], self.samples[j]['thetas'][best_in[j]])
+        j = int(np.argmax(self._arr['logLs']))   # first occurrence of the maximum, as the reference's nested argmax
+        return self.st2profile(self._pool['ss'][j], self._pool['thetas'][j])
 
     def log_marginal_posterior(self):
         """
@@ -538,7 +648,7 @@ class FixedkSampler:
         summed per state -- sums of non-negative terms only, like the reference's logsumexp, so that
         tiny marginals keep their relative accuracy.
         """
-        pooled = {key: np.concatenate([smp[key] for smp in self.samples]) for key in self.samples[-1]}
+        pooled = dict(self._arr, ss=self._pool['ss'], thetas=self._pool['thetas'])
         log_weights = pooled['log_weights'] if 'log_weights' in pooled else pooled['logLs']
         T = len(self.traj)
         n = self.model.nStates
