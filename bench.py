@@ -42,22 +42,13 @@ def build_workload(rank, n_samples, T, k, S=2, N=20, d=3, err=0.1):
     return model, traj, ss, thetas
 
 
-def cpu_baseline(model, traj, ss, thetas, T, budget_s=15.0):
-    """
-    The reference's own Cython kernel (compiled unmodified into oracle/_ref) on ONE host core,
-    driven exactly like FixedkSampler.logL drives it (a Python loop, amis.py:735-739), on a
-    bounded sample of the same batch.
-    """
+def _cpu_baseline_loop(model, traj, ss, thetas, T, budget_s):
+    """ the timed loop itself; runs in a child process (see cpu_baseline) """
     import helpers as H
     from oracle import oracle
-    try:
-        from threadpoolctl import threadpool_limits
-        limiter = threadpool_limits(limits=1)
-    except Exception:  # pragma: no cover
-        limiter = None
     ref = oracle.load_reference_cython()
     kind = 'reference'
-    states = H.expand(ss[:4096], thetas[:4096], T)
+    states = H.expand(ss[:8192], thetas[:8192], T)
 
     class M:
         pass
@@ -74,13 +65,39 @@ def cpu_baseline(model, traj, ss, thetas, T, budget_s=15.0):
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < budget_s and len(out) < len(states):
         out.append(ref(m, H.ProfileView(states[len(out)]), traj))
-    dt = time.perf_counter() - t0
-    if limiter is not None:
-        limiter.restore_original_limits()
+    return kind, time.perf_counter() - t0, np.array(out)
+
+
+def _cpu_baseline_child(argv):
+    """ `bench.py --cpu-baseline-child rank n T k S budget out.npz`: CPU only, never touches the GPU """
+    rank, n, T, k, S = (int(v) for v in argv[:5])
+    model, traj, ss, thetas = build_workload(rank, n, T, k, S=S)
+    kind, dt, out = _cpu_baseline_loop(model, traj, ss, thetas, T, float(argv[5]))
+    np.savez(argv[6], kind=kind, dt=dt, out=out)
+
+
+def cpu_baseline(rank, n, T, k, S, budget_s=15.0):
+    """
+    The reference's own Cython kernel (compiled unmodified into oracle/_ref) on ONE host core,
+    driven exactly like FixedkSampler.logL drives it (a Python loop, amis.py:735-739), on a
+    bounded sample of the same batch.  It runs in a fresh child process with the BLAS pools pinned to
+    one thread from the start: inside this process (torch loaded, pools limited after the fact) the
+    same loop is 20-35 % slower, which would flatter the GPU.
+    """
+    import subprocess
+    import tempfile
+    env = dict(os.environ, OPENBLAS_NUM_THREADS='1', OMP_NUM_THREADS='1', MKL_NUM_THREADS='1')
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, 'cpu_baseline.npz')
+        subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-child',
+                        str(rank), str(n), str(T), str(k), str(S), str(budget_s), path],
+                       env=env, check=True, timeout=budget_s + 600)
+        with np.load(path) as z:
+            kind, dt, out = str(z['kind']), float(z['dt']), np.array(z['out'])
     return dict(value=len(out) / dt, unit='evals/s', cores=1, kind=kind,
                 sample=f"first {len(out)} profiles of the rank-0 batch, T={T}, {dt:.1f} s of "
                        f"{'reference Cython MSRouse_logL (oracle/_ref)' if kind == 'reference' else 'oracle C port'}"
-                       f" in a Python loop (amis.py:735-739)"), np.array(out)
+                       f" in a Python loop (amis.py:735-739), own process, BLAS pinned to 1 thread"), out
 
 
 def main():
@@ -285,7 +302,7 @@ def main():
             result['host_buffers'] = {'value': n * reps / (time.perf_counter() - t0), 'unit': 'evals/s',
                                       'note': 'bild_logl_segments: H2D profiles + launch + D2H results + sync per step'}
         if not args.no_cpu_baseline:
-            base, ref_out = cpu_baseline(model, traj, ss, thetas, T)
+            base, ref_out = cpu_baseline(rank, n, T, k, args.states)
             result['cpu_baseline'] = base
             step(args.path)
             torch.cuda.synchronize()
@@ -301,4 +318,7 @@ def main():
 
 
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == '--cpu-baseline-child':
+        _cpu_baseline_child(sys.argv[2:])
+    else:
+        main()
