@@ -216,6 +216,23 @@ class MultiStateRouse(MultiStateModel):
         return _lib.logl_segments(self.handle(), self.trajset(trajs), seg_start, seg_state, traj_id, path=self.path)
 
     # ------------------------------------------------------------------ generative model
+    def initial_loopingprofile(self, traj):
+        """ initial guess: the per-frame best state of the factorized model (reference bild/models.py:280-293) """
+        return self.toFactorized().initial_loopingprofile(traj)
+
+    def toFactorized(self):
+        """
+        The `FactorizedModel` that draws every frame from the steady-state distance distribution of its
+        state (reference bild/models.py:352-370): Maxwell with scale^2 = w.C0.w + mean squared localization
+        error per dimension.  CPU only, cheap; not a substitute for `logL`.
+        """
+        from scipy import stats
+        err = self.localization_error
+        noise2_per_d = np.sum(np.asarray(err) ** 2) / self.d if err is not None else 0
+        w = self.measurement
+        return FactorizedModel([stats.maxwell(scale=np.sqrt(w @ C0 @ w + noise2_per_d)) for C0 in self.arrays()['C0']],
+                               d=self.d)
+
     def trajectory_from_loopingprofile(self, profile, localization_error=None, missing_frames=None, rng=None):
         """
         Sample a trajectory from the model (reference bild/models.py:295-350): steady-state

@@ -54,3 +54,19 @@ def test_matches_rouse_package_if_installed():
         w = np.zeros(N)
         w[0], w[-1] = -1, 1
         assert abs(w @ mine.steady_state()[1] @ w - w @ ref.steady_state()[1] @ w) < 1e-10
+
+
+def test_initial_loopingprofile_pins_of_the_reference():
+    """ reference tests/test_bild.py:129-133 (base implementation) and :145-151 (Rouse -> factorized guess) """
+    import bild_amd
+    from bild_amd.models import MultiStateModel
+    traj = bild_amd.Trajectory([1, 2, np.nan, 4], localization_error=[0.5])
+    model = bild_amd.MultiStateRouse(20, 1, 5, d=1)
+    assert len(MultiStateModel.initial_loopingprofile(model, traj)) == 4                  # :132-133
+    model = bild_amd.MultiStateRouse(20, 1, 5, d=1, localization_error=0.5)
+    assert np.array_equal(model.initial_loopingprofile(traj).state, [1, 0, 0, 0])         # :150-151
+    fact = model.toFactorized()                                                           # models.py:352-370
+    assert fact.nStates == 2 and fact.d == 1
+    w = model.measurement
+    for dist, C0 in zip(fact.distributions, model.arrays()['C0']):
+        assert np.isclose(dist.kwds['scale'] ** 2, w @ C0 @ w + 0.25)
