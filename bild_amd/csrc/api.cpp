@@ -123,6 +123,7 @@ struct bild_trajset {
     int d = 0;
     std::vector<TrajDesc> descs; // host copy; .x are device pointers
     int dstar_max = 1;
+    int means_max = 1; // most dimensions any covariance chain carries
     int Tmax = 0;
     bool all_valid = true;
     int device = -1;
@@ -470,7 +471,7 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
     int rc = pick_mode(m, flags, &mode);
     if (rc) return rc;
     Geometry geom;
-    if (!geometry_for(m.NP, mode, n * ts.dstar_max, &geom)) return fail(BILD_ERR_UNSUPPORTED, "no kernel for %d rows", m.NP);
+    if (!geometry_for(m.NP, mode, n * ts.dstar_max, ts.means_max, &geom)) return fail(BILD_ERR_UNSUPPORTED, "no kernel for %d rows", m.NP);
     const size_t lds = lds_bytes(m, geom, mode);
     if (lds > 160 * 1024)
         return fail(BILD_ERR_UNSUPPORTED, "model tables need %zu bytes of LDS (> 160 KiB): too many states for chain length %d", lds, m.n);
@@ -717,6 +718,7 @@ int bild_trajset_create(const bild_model *m, int n_traj, const int32_t *T, const
                 if (uniq[u] == e) td.dims[u][td.ndims[u]++] = k;
         }
         ts->dstar_max = std::max(ts->dstar_max, nu);
+        for (int u = 0; u < nu; ++u) ts->means_max = std::max(ts->means_max, (int)td.ndims[u]);
         ts->Tmax = std::max(ts->Tmax, (int)T[j]);
         off += T[j];
     }

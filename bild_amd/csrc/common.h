@@ -64,8 +64,11 @@ struct Geometry {
     int W;          // wavefronts per workgroup
     int OCC;        // wavefronts per SIMD the register allocation is bounded for
     int id;         // index into the compiled-kernel table
-    int modes;      // paths that may pick it automatically: 1 dense, 2 modal
+    int modes;      // paths that may pick it automatically: 1 dense, 2 modal; 0: only through BILD_GEOM
     int tasks_per_wave() const { return 64 / G; }
+    // mean vectors a group can carry next to the NP covariance columns (a covariance chain needs one per
+    // dimension that shares its localization error: d for d* = 1, fewer when the errors differ)
+    int mean_slots() const { return CPL * G - NP < kDMax ? CPL * G - NP : kDMax; }
 };
 
 // doubles of LDS one group needs: image of X*[C|M], NP+kDMax columns of NP rows
@@ -76,9 +79,10 @@ int launch_logl(const Geometry &g, int mode, const KParams &p, int grid, size_t 
 int launch_reduce_partials(const double *partial, double *out, int64_t n, int dstar_max, void *stream);
 // smallest compiled row count >= n_rows, or 0
 int padded_rows(int n_rows);
-// launch geometry for `ntasks` recursions of a chain padded to NP rows (several are compiled per NP:
-// few tasks per wave for small batches, many for throughput); env BILD_GEOM=<id> overrides.
-bool geometry_for(int NP, int mode, int64_t ntasks, Geometry *g);
+// launch geometry for `ntasks` recursions of a chain padded to NP rows, each with up to `means` mean vectors
+// (several are compiled per NP: few tasks per wave for small batches, many for throughput, fewer lanes per
+// task when fewer mean vectors are needed); env BILD_GEOM=<id> overrides.
+bool geometry_for(int NP, int mode, int64_t ntasks, int means, Geometry *g);
 const char *kernel_name(const Geometry &g, int mode);
 
 } // namespace bild

@@ -139,7 +139,10 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
     constexpr int MS = table_stride(NP); // LDS matrix stride
     constexpr int SB = StateBlock::size(NP);
     static_assert(NP % 2 == 0, "rows are read in pairs");
-    static_assert(CPL * G >= NP + kDMax, "not enough columns for [C | M]");
+    // mean columns a group has room for; the host only selects a geometry whose MC covers the largest
+    // number of dimensions any covariance chain of the trajectory set carries (Geometry::mean_slots)
+    constexpr int MC = (CPL * G - NP < kDMax) ? CPL * G - NP : kDMax;
+    static_assert(MC >= 1, "not enough columns for [C | M]");
 
     extern __shared__ __align__(16) double smem[];
 
@@ -166,7 +169,7 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
     for (int q = 0; q < CPL; ++q) {
         cidx[q] = gl * CPL + q;
         isC[q] = cidx[q] < NP;
-        hasImg[q] = cidx[q] < NP + kDMax; // spare columns have no LDS image (and stay zero)
+        hasImg[q] = cidx[q] < NP + MC; // spare columns have no LDS image (and stay zero)
     }
 
     const int S = p.S;
@@ -498,8 +501,9 @@ int launch_geom(int mode, const KParams &p, int grid, size_t lds, hipStream_t st
     return go(logl_kernel<NP, CPL, G, W, OCC, kDense, 2>);
 }
 
-// (id, rows, columns per lane, lanes per group, waves per workgroup, min waves per SIMD);
-// CPL * G >= NP + 3.  W is chosen so that W * (64/G) group images + the dense tables fit in
+// (id, rows, columns per lane, lanes per group, waves per workgroup, min waves per SIMD, paths);
+// CPL * G >= NP + 1: a group carries min(3, CPL * G - NP) mean vectors (G = NP + 1 / + 2 serve chains of one /
+// two dimensions -- d < 3, or localization errors that differ between dimensions -- with more tasks per wave).  W is chosen so that W * (64/G) group images + the dense tables fit in
 // 160 KiB of LDS; OCC bounds the register allocation (512 / OCC VGPRs per lane).  The table
 // may hold several geometries per NP, listed by increasing tasks per wave: geometry_for takes
 // the first one whose waves are all resident at once, else the last (densest) one.
@@ -527,7 +531,11 @@ int launch_geom(int mode, const KParams &p, int grid, size_t lds, hipStream_t st
 #define BILD_GEOMETRIES(X)     \
     X(0, 4, 1, 7, 4, 3, 3)     \
     X(1, 4, 2, 4, 4, 2, 3)     \
+    X(17, 8, 1, 9, 4, 3, 3)    \
+    X(18, 8, 1, 10, 4, 3, 3)   \
     X(2, 8, 1, 11, 4, 3, 3)    \
+    X(19, 10, 1, 11, 4, 3, 3)  \
+    X(20, 10, 1, 12, 4, 3, 3)  \
     X(3, 10, 1, 13, 4, 3, 3)   \
     X(4, 10, 2, 7, 4, 2, 3)    \
     X(5, 12, 1, 15, 4, 2, 3)   \
@@ -540,16 +548,14 @@ int launch_geom(int mode, const KParams &p, int grid, size_t lds, hipStream_t st
     X(12, 24, 1, 27, 4, 1, 3)  \
     X(13, 28, 1, 31, 4, 1, 3)  \
     X(14, 32, 1, 35, 4, 1, 3)  \
-    X(15, 10, 1, 16, 4, 3, 2)  \
-    X(16, 12, 1, 16, 4, 2, 2)
+    X(15, 10, 1, 16, 4, 3, 0)  \
+    X(16, 12, 1, 16, 4, 2, 0)
 
 constexpr Geometry kGeoms[] = {
 #define X(ID, NP, CPL, G, W, OCC, MODES) {NP, CPL, G, W, OCC, ID, MODES},
     BILD_GEOMETRIES(X)
 #undef X
 };
-constexpr int kNumGeoms = sizeof(kGeoms) / sizeof(kGeoms[0]);
-constexpr int kFirstExperimental = 15; // ids from here on are only reachable through BILD_GEOM
 
 } // namespace
 
@@ -560,23 +566,27 @@ int padded_rows(int n_rows)
     return 0;
 }
 
-bool geometry_for(int NP, int mode, int64_t ntasks, Geometry *g)
+bool geometry_for(int NP, int mode, int64_t ntasks, int means, Geometry *g)
 {
     if (const char *ov = getenv("BILD_GEOM")) {
         const int id = atoi(ov);
-        if (id >= 0 && id < kNumGeoms && kGeoms[id].NP == NP) {
-            *g = kGeoms[id];
-            return true;
-        }
+        for (const Geometry &c : kGeoms)
+            if (c.id == id && c.NP == NP && c.mean_slots() >= means) {
+                *g = c;
+                return true;
+            }
     }
-    // candidates are listed by increasing tasks per wave: take the first one whose waves are all
-    // resident at once (256 CUs x 4 SIMDs x OCC waves); if none is, the one with the smallest
+    // candidates are listed by increasing lanes per task, then increasing tasks per wave.  Of those with room
+    // for `means` mean vectors, one column per lane and the fewest lanes come first; take the first one whose
+    // waves are all resident at once (256 CUs x 4 SIMDs x OCC waves); if none is, the one with the smallest
     // (rounds of resident waves) x (cost of a frame ~ CPL + c0), c0 = per-frame overhead in units of
     // one column's work (dense: FMA-bound, ~0; modal: ~2)
     const Geometry *best = nullptr;
     int64_t best_cost = 0;
     for (const Geometry &c : kGeoms) {
-        if (c.NP != NP || c.id >= kFirstExperimental || !(c.modes & (mode == kDense ? 1 : 2))) continue;
+        if (c.NP != NP || c.mean_slots() < means || !(c.modes & (mode == kDense ? 1 : 2))) continue;
+        // of the one-column geometries only the tightest fit is a candidate (the wider ones idle lanes)
+        if (best && best->CPL == 1 && c.CPL == 1) continue;
         const int64_t waves = (ntasks + c.tasks_per_wave() - 1) / c.tasks_per_wave();
         const int64_t slots = 1024 * (int64_t)c.OCC;
         if (waves <= slots) {
