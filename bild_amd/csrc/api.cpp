@@ -107,6 +107,7 @@ struct bild_model {
     Mat lam, sigd, Q, wq, R, C0q, M0q, Gq; // S*n, S*n, S*n*n, S*n, S*S*n*n, S*n*n, S*n*d, S*n*d
     // packed for the kernels
     int NP = 0; // padded row count; the launch geometry is chosen per batch (geometry_for)
+    bool wide = false; // NP > kMaxNP: LDS-resident kernel (wide.hip), modal path only
     Mat blob_states[2], blob_tab[2];
     // device residency
     mutable std::mutex mu;      // device residency and workspace growth
@@ -377,8 +378,12 @@ int analyse(bild_model &m)
 
     // ---- pack --------------------------------------------------------------------------
     m.NP = padded_rows(n);
-    if (!m.NP)
-        return fail(BILD_ERR_UNSUPPORTED, "chain of %d effective modes exceeds the compiled kernels (max %d)", n, kMaxNP);
+    if (!m.NP) {
+        if (n > kWideMaxNP)
+            return fail(BILD_ERR_UNSUPPORTED, "chain of %d effective modes exceeds the kernels (max %d)", n, kWideMaxNP);
+        m.NP = (n + 1) & ~1;
+        m.wide = true;
+    }
     const int NP = m.NP;
     const int SB = StateBlock::size(NP);
     const int MS = table_stride(NP);
@@ -470,11 +475,19 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
     int mode;
     int rc = pick_mode(m, flags, &mode);
     if (rc) return rc;
-    Geometry geom;
-    if (!geometry_for(m.NP, mode, n * ts.dstar_max, ts.means_max, &geom)) return fail(BILD_ERR_UNSUPPORTED, "no kernel for %d rows", m.NP);
-    const size_t lds = lds_bytes(m, geom, mode);
-    if (lds > 160 * 1024)
-        return fail(BILD_ERR_UNSUPPORTED, "model tables need %zu bytes of LDS (> 160 KiB): too many states for chain length %d", lds, m.n);
+    Geometry geom{};
+    size_t lds = 0;
+    if (m.wide) {
+        if (mode != kModal)
+            return fail(BILD_ERR_UNSUPPORTED, "chains of more than %d effective modes (here %d) run on the modal path only%s%s", kMaxNP,
+                        m.n, m.modal_ok ? "" : ", which is unavailable: ", m.modal_ok ? "" : m.modal_why.c_str());
+    } else {
+        if (!geometry_for(m.NP, mode, n * ts.dstar_max, ts.means_max, &geom))
+            return fail(BILD_ERR_UNSUPPORTED, "no kernel for %d rows", m.NP);
+        lds = lds_bytes(m, geom, mode);
+        if (lds > 160 * 1024)
+            return fail(BILD_ERR_UNSUPPORTED, "model tables need %zu bytes of LDS (> 160 KiB): too many states for chain length %d", lds, m.n);
+    }
 
     KParams p{};
     p.states = m.d_states[mode];
@@ -501,7 +514,7 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
     }
     p.out = target;
 
-    const int64_t tasks_per_block = (int64_t)geom.W * geom.tasks_per_wave();
+    const int64_t tasks_per_block = m.wide ? 1 : (int64_t)geom.W * geom.tasks_per_wave();
     int64_t blocks = (p.ntasks + tasks_per_block - 1) / tasks_per_block;
     const int grid = (int)std::min<int64_t>(std::max<int64_t>(blocks, 1), 256 * 16);
 
@@ -516,13 +529,13 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, st));
     }
-    int lrc = launch_logl(geom, mode, p, grid, lds, (void *)st);
+    int lrc = m.wide ? launch_logl_wide(m.NP, p, grid, (void *)st) : launch_logl(geom, mode, p, grid, lds, (void *)st);
     if (lrc != 0) return fail(BILD_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
     if (timing) {
         HIP_TRY(hipEventRecord(e1, st));
         std::lock_guard<std::mutex> lk(g_time_mu);
         g_time_events.emplace_back(e0, e1);
-        g_time_name = kernel_name(geom, mode);
+        g_time_name = m.wide ? "logl_wide_kernel" : kernel_name(geom, mode);
     }
     if (ts.dstar_max > 1) {
         lrc = launch_reduce_partials(target, d_out, n, ts.dstar_max, (void *)st);

@@ -6,7 +6,8 @@ namespace bild {
 
 constexpr int kDMax = 3;      // spatial dimensions supported (reference default d = 3, models.py:222)
 constexpr int kMaxWaves = 4;  // wavefronts per workgroup (fewer for long chains: LDS capacity)
-constexpr int kMaxNP = 32;    // largest padded chain length with a compiled kernel
+constexpr int kMaxNP = 32;    // largest padded chain length with a register-resident kernel (kernels.hip)
+constexpr int kWideMaxNP = 128; // largest padded chain length at all: LDS-resident state (wide.hip), modal path only
 
 enum Mode : int { kDense = 0, kModal = 1 };
 
@@ -84,5 +85,8 @@ int padded_rows(int n_rows);
 // task when fewer mean vectors are needed); env BILD_GEOM=<id> overrides.
 bool geometry_for(int NP, int mode, int64_t ntasks, int means, Geometry *g);
 const char *kernel_name(const Geometry &g, int mode);
+// chains of more than kMaxNP modes (wide.hip): one task per workgroup, state in LDS
+size_t wide_lds_bytes(int NP);
+int launch_logl_wide(int NP, const KParams &p, int grid, void *stream);
 
 } // namespace bild

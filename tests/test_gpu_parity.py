@@ -115,6 +115,49 @@ def test_chain_lengths(built_lib, N):
             assert np.max(np.abs(got - want)) < TOL, (N, reduce, path)
 
 
+@pytest.mark.parametrize('case', ['N48_full', 'N100_end2end', 'N90_3state', 'N128_full', 'N40_force', 'N256_end2end'])
+def test_long_chains(built_lib, case):
+    """
+    more than 32 effective modes: the LDS-resident kernel (wide.hip) against the oracle -- missing frames,
+    two localization errors, three states, an external force, the largest supported size, several trajectories
+    """
+    import bild_amd
+    from bild_amd import _lib
+    from oracle import oracle
+    rng = np.random.default_rng(len(case) + 7)
+    S, T, nprof, k, reduce, err, d = 2, 90, 12, 3, True, [0.1, 0.2], 2
+    if case == 'N48_full':
+        N, reduce = 48, False
+    elif case == 'N100_end2end':
+        N = 100
+    elif case == 'N90_3state':
+        N, S, d, err = 90, 3, 3, [0.1, 0.1, 0.3]
+    elif case == 'N128_full':
+        N, reduce, T, nprof, d, err = 128, False, 40, 4, 1, [0.15]
+    elif case == 'N40_force':
+        N, reduce, d, err = 40, False, 3, [0.1, 0.1, 0.2]
+    else:
+        N, T, nprof, d, err = 256, 40, 4, 1, [0.15]
+    model = bild_amd.MultiStateRouse(N, 1, 2, d=d, looppositions=H.LOOPS[S] if S == 3 else (None, (0, -1)),
+                                     localization_error=err)
+    if case == 'N40_force':
+        for mi, mod in enumerate(model.models):
+            mod.F[0, :] = [0.5, -0.25, 0.1 * (mi + 1)]
+            mod.F[-1, :] = [-0.5, 0.25, -0.1 * (mi + 1)]
+            mod.F[7, 1] = 0.3
+            mod.update_dynamics()
+    a = model.arrays()
+    model._handle = _lib.ModelHandle(a['B'], a['G'], a['Sig'], a['M0'], a['C0'], model.measurement, reduce=reduce)
+    assert model.handle().query(_lib.Q_NEFF) > 32
+    trajs = [model.trajectory_from_loopingprofile(H.random_profile(rng, T + 7 * j, S, 25), missing_frames=0.1 * j, rng=rng)
+             for j in range(2)]
+    for j, traj in enumerate(trajs):
+        ss, thetas = H.candidate_profiles(rng, nprof, k, S)
+        want = oracle.logl_batch(a, model.measurement, model.localization_error, traj[:], H.expand(ss, thetas, len(traj)))
+        got = model.logL_st_batch(ss, thetas, traj)
+        assert np.max(np.abs(got - want)) < TOL, (case, j, np.max(np.abs(got - want)))
+
+
 def test_multi_trajectory_batch(built_lib):
     """ samples spread over several trajectories of different length / noise / masks """
     import bild_amd
@@ -184,10 +227,13 @@ def test_error_paths(built_lib):
     with pytest.raises(AssertionError):        # wrong spatial dimension (reference asserts shapes, pyx:165-166)
         model.logL_batch(np.zeros((1, 10), int), bild_amd.Trajectory(np.zeros((10, 3))))
     assert model.logL_batch(np.zeros((0, 10), int), traj).shape == (0,)
-    big = bild_amd.MultiStateRouse(40, 1, 2, d=1, localization_error=0.1)     # 40 modes after NO reduction
+    big = bild_amd.MultiStateRouse(130, 1, 2, d=1, localization_error=0.1)    # 130 modes after NO reduction
     a = big.arrays()
-    with pytest.raises(_lib.BildAmdError):                                      # outside the compiled envelope: loud
+    with pytest.raises(_lib.BildAmdError):                                      # outside the envelope: loud
         _lib.ModelHandle(a['B'], a['G'], a['Sig'], a['M0'], a['C0'], big.measurement, reduce=False)
+    long = bild_amd.MultiStateRouse(80, 1, 2, d=1, localization_error=0.1, path='dense')   # 40 modes: modal only
+    with pytest.raises(_lib.BildAmdError):
+        long.logL_batch(np.zeros((1, 10), int), bild_amd.Trajectory(np.zeros((10, 1))))
 
 
 def test_device_pointer_entry_point(built_lib):
