@@ -67,6 +67,10 @@ int bild_device_count(int *count);
  *   N  monomers, d spatial dimensions (1..3), S states
  *   B, Sig, C0 : S x N x N     G, M0 : S x N x d     w : N
  *
+ * Envelope: d <= 3, S <= 255, and at most 128 modes left by the (exact) invariant-subspace
+ * reduction -- N <= 256 monomers for the default end-to-end measurement, N <= 128 for an
+ * arbitrary w; above 32 modes only the modal path exists.  Outside: BILD_ERR_UNSUPPORTED.
+ *
  * Host analysis only (eigenbases for the modal path, packing); no GPU is needed to
  * create a model.  Device copies are made lazily on the device that is current when an
  * evaluation first uses the model.  The caller keeps ownership of all inputs.
