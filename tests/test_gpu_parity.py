@@ -424,3 +424,27 @@ def test_baseline_config4_shape(built_lib):
         got = model.logL_segments(seg_start, seg_state, trajs, tid)
         assert np.all(np.isfinite(got))
         assert _spot_check(model, trajs, seg_start, seg_state, tid, got, rng, 24, [T] * len(trajs)) < TOL
+
+
+@pytest.mark.parametrize('case', ['long_T', 'many_switches', 'many_tasks'])
+def test_extreme_shapes(built_lib, case):
+    """ maximum sizes: a very long trajectory, more switches than a register-resident table would hold, a huge batch """
+    import bild_amd
+    from oracle import oracle
+    rng = np.random.default_rng({'long_T': 1, 'many_switches': 2, 'many_tasks': 3}[case])
+    model = bild_amd.MultiStateRouse(20, 1, 5, d=3, localization_error=0.1)
+    if case == 'long_T':
+        T, n, k, check = 60_000, 48, 6, 6
+    elif case == 'many_switches':
+        T, n, k, check = 2_000, 256, 400, 24
+    else:
+        T, n, k, check = 12, 3_000_000, 2, 200
+    traj = model.trajectory_from_loopingprofile(H.random_profile(rng, T, 2, max(T // 7, 2)), missing_frames=0.05, rng=rng)
+    ss, thetas = H.candidate_profiles(rng, n, k, 2)
+    got = model.logL_st_batch(ss, thetas, traj)
+    assert got.shape == (n,) and np.all(np.isfinite(got))
+    pick = rng.choice(n, check, replace=False)
+    want = oracle.logl_batch(model.arrays(), model.measurement, model.localization_error, traj[:],
+                             H.expand(ss[pick], thetas[pick], T))
+    # the running sums are ~60x longer than in the T = 1000 cases: the tolerance scales with T
+    assert np.max(np.abs(got[pick] - want)) < TOL * max(1, T // 1000), case
