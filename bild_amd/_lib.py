@@ -55,6 +55,17 @@ _SIGNATURES = {
     'bild_flop_count': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, _ip, ctypes.c_uint, _dp, _dp]),
     'bild_kernel_timing': (ctypes.c_int, [ctypes.c_int]),
     'bild_kernel_timing_read': (ctypes.c_int, [_dp, ctypes.POINTER(ctypes.c_int64), ctypes.c_char_p, ctypes.c_int]),
+    # host-side AMIS bookkeeping (amis_host.cpp)
+    'bild_amis_create': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _vp, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                        _dp, _dp, ctypes.POINTER(_vp)]),
+    'bild_amis_destroy': (ctypes.c_int, [_vp]),
+    'bild_amis_error': (ctypes.c_char_p, [_vp]),
+    'bild_amis_pool_size': (ctypes.c_int64, [_vp]),
+    'bild_amis_num_proposals': (ctypes.c_int64, [_vp]),
+    'bild_amis_params': (ctypes.c_int, [_vp, ctypes.c_int64, _dp, _dp]),
+    'bild_amis_pool': (ctypes.c_int, [_vp, ctypes.c_int, _dp]),
+    'bild_amis_sample_traces': (ctypes.c_int, [_vp, ctypes.c_int64, _dp, _vp]),
+    'bild_amis_step': (ctypes.c_int, [_vp, ctypes.c_int64, _dp, _vp, _dp, _dp]),
 }
 
 _lib = None
@@ -208,3 +219,70 @@ def kernel_timing_read():
     name = ctypes.create_string_buffer(128)
     check(lib().bild_kernel_timing_read(ctypes.byref(ms), ctypes.byref(cnt), name, 128))
     return ms.value, cnt.value, name.value.decode()
+
+
+class AmisCore:
+    """
+    Host-side bookkeeping of one fixed-k AMIS sampler in native code (include/bild_amd.h, "host-side AMIS
+    bookkeeping"; csrc/amis_host.cpp).  No GPU involved.  `bild_amd.amis.FixedkSampler` drives it; the NumPy
+    formulation of the same bookkeeping lives there as the specification.
+    """
+    POOL = {'logLs': 0, 'logδs': 1, 'cur_log_proposal': 2, 'log_weights': 3}
+
+    def __init__(self, transitions, a0, logp0, concentration_brake, polarization_brake, logprior):
+        trans = np.ascontiguousarray(np.asarray(transitions) != 0, dtype=np.uint8)
+        self.n = trans.shape[0]
+        self.k1 = len(a0)
+        logp0 = f64(logp0)
+        assert logp0.shape == (self.n, self.k1)
+        self._h = _vp()
+        code = lib().bild_amis_create(self.k1, self.n, trans.ctypes.data_as(_vp), float(concentration_brake),
+                                      float(polarization_brake), float(logprior), dptr(f64(a0)), dptr(logp0),
+                                      ctypes.byref(self._h))
+        if code != OK:
+            raise BildAmdError(code, "bild_amis_create failed")
+
+    def __del__(self):
+        h, self._h = getattr(self, '_h', None), None
+        if h:
+            try:
+                lib().bild_amis_destroy(h)
+            except Exception:  # pragma: no cover  (interpreter shutdown)
+                pass
+
+    def __len__(self):
+        return int(lib().bild_amis_pool_size(self._h))
+
+    def params(self, which=-1):
+        a, logp = np.empty(self.k1), np.empty((self.n, self.k1))
+        if lib().bild_amis_params(self._h, which, dptr(a), dptr(logp)) != OK:
+            raise IndexError(which)
+        return a, logp
+
+    def pool(self, key):
+        out = np.empty(len(self))
+        if lib().bild_amis_pool(self._h, self.POOL[key], dptr(out)) != OK:
+            raise KeyError(key)
+        return out
+
+    def sample_traces(self, u):
+        """ u: (k1, N) uniform random numbers -> (N, k1) int traces from the current proposal """
+        u = f64(u)
+        assert u.ndim == 2 and u.shape[0] == self.k1
+        thetas = np.empty((u.shape[1], self.k1), dtype=np.int64)
+        code = lib().bild_amis_sample_traces(self._h, u.shape[1], dptr(u), thetas.ctypes.data_as(_vp))
+        if code != OK:
+            raise BildAmdError(code, "bild_amis_sample_traces failed")
+        return thetas
+
+    def step(self, ss, thetas, logLs):
+        """ -> (logev, dlogev, KL); RuntimeError("Iteration did not converge") as the reference raises it """
+        ss, logLs = f64(ss), f64(logLs)
+        thetas = np.ascontiguousarray(thetas, dtype=np.int64)
+        assert ss.shape == thetas.shape == (len(logLs), self.k1)
+        ev = np.empty(3)
+        code = lib().bild_amis_step(self._h, len(logLs), dptr(ss), thetas.ctypes.data_as(_vp), dptr(logLs), dptr(ev))
+        if code != OK:
+            msg = lib().bild_amis_error(self._h).decode()
+            raise RuntimeError(msg) if 'converge' in msg else BildAmdError(code, msg)
+        return tuple(ev)

@@ -407,9 +407,11 @@ class FixedkSampler:
                  polarization_brake=1e-3,
                  max_fev=20000,
                  max_fcomplete=1000,
+                 native=True,
                  ):
         self.k = k
         self.N = N
+        self.native = native
         self.brakes = (concentration_brake, polarization_brake)
         self.max_fev = max_fev
         self.max_fcomplete = max_fcomplete
@@ -434,8 +436,17 @@ class FixedkSampler:
         # ('logLs', 'logδs', 'cur_log_proposal', 'log_weights'); `_sizes` the number of samples per step.
         self._sizes = []
         self._pool = None
-        self._arr = {}
+        self._arr_np = {}
+        self._arr_cache = (None, None)
         self.samples = _SampleList(self)
+        # The bookkeeping of `step` exists twice: in NumPy below (the specification, `native=False`) and as one
+        # pass of native host code over the pooled samples (csrc/amis_host.cpp, the default), compared step by
+        # step in tests/test_amis.py.
+        self._core = None
+        if native:
+            from . import _lib
+            self._core = _lib.AmisCore(model.transitions, self.parameters[0][0], self.parameters[0][1],
+                                       concentration_brake, polarization_brake, self.logprior)
         # per proposal: concentration vector and CFC.lookup_tables, stacked
         self._As = np.empty((0, self.k + 1))
         self._heads = np.empty((0, self.cfc.n))
@@ -446,6 +457,20 @@ class FixedkSampler:
             self.fix_exhaustive()
         except FixedkSampler.ExhaustionImpractical:
             pass
+
+    @property
+    def _arr(self):
+        """ pooled per-sample arrays; with the native core they are fetched when somebody looks """
+        if self._core is None or len(self._core) == 0:
+            return self._arr_np
+        stamp = len(self._sizes)
+        if self._arr_cache[0] != stamp:
+            self._arr_cache = (stamp, {key: self._core.pool(key) for key in self._core.POOL})
+        return self._arr_cache[1]
+
+    @_arr.setter
+    def _arr(self, value):
+        self._arr_np = value
 
     # -- profile encoding -----------------------------------------------------------------
     def st2profile(self, s, theta):
@@ -531,6 +556,8 @@ class FixedkSampler:
             return False
 
         a_cur, logp_cur = self.parameters[-1]
+        if self._core is not None:
+            return self._step_native(a_cur)
 
         # The bookkeeping below is the reference's, evaluated on pooled arrays: one call per quantity
         # and step instead of one per earlier sample / earlier proposal (with the likelihood on the GPU
@@ -624,6 +651,29 @@ class FixedkSampler:
                   - logev + self.logprior)
         self.evidences.append((logev, dlogev, KL))
 
+        if (len(self._sizes) + 1) * self.N >= self.max_fev:
+            self.exhausted = True
+        return True
+
+    def _step_native(self, a_cur):
+        """
+        `step` with the bookkeeping in native code.  The random numbers are drawn here, from the global NumPy
+        stream in the reference's order: the Dirichlet draws, then what ``np.random.choice`` consumes for the
+        first state of every trace (one uniform number each), then ``np.random.rand(N, 1)`` per later slot --
+        as one block, which is the same stream.
+        """
+        new_ss = self.dirichlet.sample(a_cur, self.N)
+        new_thetas = self._core.sample_traces(np.random.random_sample((self.k + 1, self.N)))
+        new_logLs = self.logL(new_ss, new_thetas)
+        if not self._sizes:
+            self._pool = {'ss': new_ss, 'thetas': new_thetas}
+        else:
+            self._pool = {'ss': np.concatenate([self._pool['ss'], new_ss]),
+                          'thetas': np.concatenate([self._pool['thetas'], new_thetas])}
+        self._sizes.append(len(new_ss))
+        evidence = self._core.step(new_ss, new_thetas, new_logLs)    # RuntimeError if the CFC fit does not converge
+        self.parameters.append(self._core.params(-1))
+        self.evidences.append(evidence)
         if (len(self._sizes) + 1) * self.N >= self.max_fev:
             self.exhausted = True
         return True

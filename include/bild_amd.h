@@ -176,6 +176,39 @@ int bild_flop_count(const bild_model *m, const bild_trajset *ts, int64_t n,
 int bild_kernel_timing(int enable);
 int bild_kernel_timing_read(double *total_ms, int64_t *launches, char *name, int name_len);
 
+/* ------------------------------------------------ host-side AMIS bookkeeping -------
+ * SURVEY section 8, row f-1.  Plain host code (no GPU): everything reference
+ * bild/amis.py FixedkSampler.step (amis.py:805-906) does once the likelihood of the new
+ * batch is known -- mixture denominators of all samples drawn so far, weights, refit of
+ * the Dirichlet (amis.py:110-151) and CFC (amis.py:284-399) proposals, brakes
+ * (amis.py:856-874), evidence / standard error / KL (amis.py:876-903) -- in one pass over
+ * the pooled samples.  Random numbers are drawn by the caller (NumPy stream, reference
+ * order).  bild_amd/amis.py holds the same bookkeeping in NumPy as the specification.
+ *
+ *   k1 = k + 1 intervals, n states, transitions[from*n + to] != 0 where allowed
+ *   a0 (k1), logp0 (n x k1, [state][slot]): the initial proposal
+ */
+typedef struct bild_amis bild_amis;
+int bild_amis_create(int k1, int n, const uint8_t *transitions, double concentration_brake,
+                     double polarization_brake, double logprior, const double *a0,
+                     const double *logp0, bild_amis **out);
+int bild_amis_destroy(bild_amis *m);
+const char *bild_amis_error(const bild_amis *m);
+int64_t bild_amis_pool_size(const bild_amis *m);
+int64_t bild_amis_num_proposals(const bild_amis *m);
+/* proposal `which` (negative: from the end); either output may be NULL */
+int bild_amis_params(const bild_amis *m, int64_t which, double *a, double *logp);
+/* pooled per-sample arrays: 0 logLs, 1 log mixture denominators, 2 log density under the
+ * current proposal, 3 log weights */
+int bild_amis_pool(const bild_amis *m, int what, double *out);
+/* traces from the current proposal (amis.py:223-256); u: k1 blocks of N uniform numbers */
+int bild_amis_sample_traces(const bild_amis *m, int64_t N, const double *u, int64_t *thetas);
+/* one iteration: ss (N x k1), thetas (N x k1), logLs (N) -> evidence[3] = (logev, dlogev, KL);
+ * a CFC fit that does not converge returns BILD_ERR_INVALID with
+ * bild_amis_error() == "Iteration did not converge" (the reference raises RuntimeError) */
+int bild_amis_step(bild_amis *m, int64_t N, const double *ss, const int64_t *thetas,
+                   const double *logLs, double *evidence);
+
 #ifdef __cplusplus
 }
 #endif
