@@ -66,6 +66,7 @@ _SIGNATURES = {
     'bild_amis_pool': (ctypes.c_int, [_vp, ctypes.c_int, _dp]),
     'bild_amis_sample_traces': (ctypes.c_int, [_vp, ctypes.c_int64, _dp, _vp]),
     'bild_amis_step': (ctypes.c_int, [_vp, ctypes.c_int64, _dp, _vp, _dp, _dp]),
+    'bild_choice_counts': (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, _dp, _dp, _dp, ctypes.c_double, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None
@@ -286,3 +287,24 @@ class AmisCore:
             msg = lib().bild_amis_error(self._h).decode()
             raise RuntimeError(msg) if 'converge' in msg else BildAmdError(code, msg)
         return tuple(ev)
+
+
+def choice_counts(rvs, mu, dmu, dE, omit=None, want_dn=True):
+    """
+    histograms of the "best k" over the rows of the common random sample (bild_choice_counts):
+    (n0, Dn or None, n_omit or None)
+    """
+    rvs, mu, dmu = f64(rvs), f64(mu), f64(dmu)
+    samplesize, kmax = rvs.shape
+    n0 = np.zeros(kmax, dtype=np.int64)
+    dn = np.zeros((kmax, kmax), dtype=np.int64) if want_dn else None
+    flags = n_omit = None
+    if omit is not None:
+        flags = np.zeros(kmax, dtype=np.uint8)
+        flags[omit] = 1
+        n_omit = np.zeros(kmax, dtype=np.int64)
+    vp = lambda a: None if a is None else a.ctypes.data_as(_vp)
+    code = lib().bild_choice_counts(samplesize, kmax, dptr(rvs), dptr(mu), dptr(dmu), float(dE), vp(flags), vp(n0), vp(dn), vp(n_omit))
+    if code != OK:
+        raise BildAmdError(code, "bild_choice_counts failed")
+    return n0, dn, n_omit

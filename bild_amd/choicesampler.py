@@ -58,7 +58,15 @@ class ChoiceSampler:
         return np.nanargmax(top - self.dE - x <= 0, axis=1)
 
     def Dn(self):
-        """ (k_change, k) expected change of the choice histogram per extra step (bild/choicesampler.py:155-169) """
+        """
+        (k_change, k) expected change of the choice histogram per extra step (bild/choicesampler.py:155-169):
+        2 k_max evaluations of the whole sample in the reference, one pass of native host code here
+        (`Dn_numpy` is the same thing in array operations; tests compare them).
+        """
+        from . import _lib
+        return _lib.choice_counts(self._scaled_rvs, self.muhat, self.Dmu, self.dE)[1]
+
+    def Dn_numpy(self):
         counts = []
         for step in (-0.5, 0.5):
             ks = np.array([self.evaluate(k, step) for k in range(self.kmax)])       # (k_change, samp)
@@ -75,8 +83,8 @@ class ChoiceSampler:
         Information carried by the positions ``omit_k``: KL(full || omitted)
         (bild/choicesampler.py:183-210).
         """
-        ks = self.evaluate(omit_k=omit_k)
-        n_without = np.sum(ks[:, None] == np.arange(self.kmax)[None, :], axis=0)
+        from . import _lib
+        n_without = _lib.choice_counts(self._scaled_rvs, self.muhat, self.Dmu, self.dE, omit=omit_k, want_dn=False)[2]
         n_without = n_without / np.sum(n_without) * self.samplesize
         Dn = self.n0 - n_without
         Dn[omit_k] = 0  # the omitted slots themselves would contribute an infinite divergence

@@ -478,4 +478,55 @@ int bild_amis_step(bild_amis *m, int64_t N, const double *ss, const int64_t *the
     return BILD_OK;
 }
 
+// Choice of the next k in the adaptive-k loop (reference bild/choicesampler.py:115-210): for every row of the
+// common random sample the "best k" is the smallest k whose perturbed evidence x_k = rvs_k + mu_k lies within dE
+// of the row maximum (NaN entries -- omitted k -- are ignored, as np.nanmax / np.nanargmax do).  One pass gives
+//   n0[k]        histogram of the best k,
+//   dn[kc][k]    histogram with mu[kc] + dmu[kc]/2 minus histogram with mu[kc] - dmu[kc]/2   (ChoiceSampler.Dn),
+//   n_omit[k]    histogram with the entries flagged in `omit` ignored                            (KLD_omitK),
+// instead of 2 kmax + 2 passes of array operations.  Any output may be NULL.
+int bild_choice_counts(int64_t samplesize, int kmax, const double *rvs, const double *mu, const double *dmu, double dE,
+                       const uint8_t *omit, int64_t *n0, int64_t *dn, int64_t *n_omit)
+{
+    if (samplesize < 0 || kmax < 1 || !rvs || !mu) return BILD_ERR_INVALID;
+    if (dn && !dmu) return BILD_ERR_INVALID;
+    if (n0) std::fill(n0, n0 + kmax, 0);
+    if (dn) std::fill(dn, dn + (size_t)kmax * kmax, 0);
+    if (n_omit) std::fill(n_omit, n_omit + kmax, 0);
+    std::vector<double> x(kmax);
+    // first k with top - dE - x_k <= 0 over the entries that are not NaN; 0 if there is none (argmax of all-False)
+    auto best = [&](const double *v) {
+        double top = -kInf;
+        bool any = false;
+        for (int k = 0; k < kmax; ++k)
+            if (!std::isnan(v[k])) {
+                top = any ? std::max(top, v[k]) : v[k];
+                any = true;
+            }
+        for (int k = 0; k < kmax; ++k)
+            if (top - dE - v[k] <= 0) return k; // false for NaN
+        return 0;
+    };
+    for (int64_t r = 0; r < samplesize; ++r) {
+        const double *row = rvs + (size_t)r * kmax;
+        for (int k = 0; k < kmax; ++k) x[k] = row[k] + mu[k];
+        if (n0) n0[best(x.data())] += 1;
+        if (dn)
+            for (int kc = 0; kc < kmax; ++kc) {
+                const double keep = x[kc];
+                x[kc] = row[kc] + (mu[kc] + 0.5 * dmu[kc]);
+                dn[(size_t)kc * kmax + best(x.data())] += 1;
+                x[kc] = row[kc] + (mu[kc] + -0.5 * dmu[kc]);
+                dn[(size_t)kc * kmax + best(x.data())] -= 1;
+                x[kc] = keep;
+            }
+        if (n_omit && omit) {
+            for (int k = 0; k < kmax; ++k)
+                if (omit[k]) x[k] = std::numeric_limits<double>::quiet_NaN();
+            n_omit[best(x.data())] += 1;
+        }
+    }
+    return BILD_OK;
+}
+
 } // extern "C"

@@ -209,6 +209,14 @@ int bild_amis_sample_traces(const bild_amis *m, int64_t N, const double *u, int6
 int bild_amis_step(bild_amis *m, int64_t N, const double *ss, const int64_t *thetas,
                    const double *logLs, double *evidence);
 
+/* Histograms behind the choice of the next k in the adaptive-k loop (reference
+ * bild/choicesampler.py:115-210): rvs (samplesize x kmax) common random sample, mu (kmax)
+ * evidence estimates (NaN = ignored), dmu (kmax) natural step sizes, omit (kmax) flags or
+ * NULL.  Outputs (any may be NULL): n0[kmax], dn[kmax][kmax], n_omit[kmax]. */
+int bild_choice_counts(int64_t samplesize, int kmax, const double *rvs, const double *mu,
+                       const double *dmu, double dE, const uint8_t *omit,
+                       int64_t *n0, int64_t *dn, int64_t *n_omit);
+
 #ifdef __cplusplus
 }
 #endif

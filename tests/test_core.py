@@ -186,3 +186,28 @@ def test_run_batched_task_errors():
     assert threading.active_count() == before          # nobody is left parked
     out = run_batched(trajs, model, loop, return_exceptions=True)
     assert out[0] == 0. and out[2] == 0. and isinstance(out[1], RuntimeError)
+
+
+def test_choice_counts_native_equals_numpy():
+    """ bild_choice_counts against the array formulation of reference bild/choicesampler.py:115-210 """
+    from bild_amd.choicesampler import ChoiceSampler
+    rng = np.random.default_rng(4)
+    for kmax, with_inf in ((1, False), (4, False), (7, True)):
+        mu = rng.normal(-100, 2, size=kmax)
+        if with_inf:
+            mu[-1] = -np.inf               # a sampler with k >= T reports -inf evidence (amis.py:641-648)
+        shat = rng.random(kmax) + 0.01
+        nsteps = np.where(rng.random(kmax) < 0.3, np.inf, rng.integers(3, 50, size=kmax).astype(float))
+        np.random.seed(9)
+        cs = ChoiceSampler(mu, shat, nsteps, dE=1.5, samplesize=3000)
+        assert np.array_equal(cs.Dn(), cs.Dn_numpy())
+        assert np.array_equal(np.bincount(cs.bestk, minlength=kmax), cs.n0)
+        for omit in ([0], list(range(max(kmax - 2, 0), kmax))):
+            if len(omit) >= kmax:
+                continue
+            ks = cs.evaluate(omit_k=omit)
+            n_without = np.sum(ks[:, None] == np.arange(kmax)[None, :], axis=0)
+            n_without = n_without / np.sum(n_without) * cs.samplesize
+            Dn = cs.n0 - n_without
+            Dn[omit] = 0
+            assert np.isclose(cs.KLD_omitK(omit), 0.5 / cs.samplesize * np.sum(Dn ** 2 / (n_without + 1)), rtol=1e-13)
