@@ -64,6 +64,7 @@ _SIGNATURES = {
     'bild_amis_num_proposals': (ctypes.c_int64, [_vp]),
     'bild_amis_params': (ctypes.c_int, [_vp, ctypes.c_int64, _dp, _dp]),
     'bild_amis_pool': (ctypes.c_int, [_vp, ctypes.c_int, _dp]),
+    'bild_amis_restore': (ctypes.c_int, [_vp, ctypes.c_int64, _dp, _dp, ctypes.c_int64, _dp, _vp, _dp, _dp, _dp, _dp]),
     'bild_amis_sample_traces': (ctypes.c_int, [_vp, ctypes.c_int64, _dp, _vp]),
     'bild_amis_step': (ctypes.c_int, [_vp, ctypes.c_int64, _dp, _vp, _dp, _dp]),
     'bild_choice_counts': (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, _dp, _dp, _dp, ctypes.c_double, _vp, _vp, _vp, _vp]),
@@ -265,6 +266,19 @@ class AmisCore:
         if lib().bild_amis_pool(self._h, self.POOL[key], dptr(out)) != OK:
             raise KeyError(key)
         return out
+
+    def restore(self, parameters, ss, thetas, arrays):
+        """ load saved state into a freshly created core: further proposals [(a, logp), ...] and the pooled samples """
+        Q = len(parameters)
+        a = f64(np.array([p[0] for p in parameters]).reshape(Q, self.k1))
+        logp = f64(np.array([p[1] for p in parameters]).reshape(Q, self.n, self.k1))
+        ss = f64(np.asarray(ss).reshape(-1, self.k1))
+        thetas = np.ascontiguousarray(np.asarray(thetas).reshape(-1, self.k1), dtype=np.int64)
+        cols = [f64(arrays[key]) for key in ('logLs', 'logδs', 'cur_log_proposal', 'log_weights')] if len(ss) else [f64([])] * 4
+        code = lib().bild_amis_restore(self._h, Q, dptr(a), dptr(logp), len(ss), dptr(ss), thetas.ctypes.data_as(_vp),
+                                       *(dptr(c) for c in cols))
+        if code != OK:
+            raise BildAmdError(code, "bild_amis_restore failed")
 
     def sample_traces(self, u):
         """ u: (k1, N) uniform random numbers -> (N, k1) int traces from the current proposal """

@@ -458,6 +458,28 @@ class FixedkSampler:
         except FixedkSampler.ExhaustionImpractical:
             pass
 
+    # -- pickling / copying: the native core is rebuilt from the pooled arrays ---------------------------
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        if state.get('_core') is not None:
+            state['_arr_np'] = dict(self._arr)
+            state['_arr_cache'] = (None, None)
+            state['_core'] = len(self._core) > 0      # True: restore the pool as well
+        return state
+
+    def __setstate__(self, state):
+        had_core = state.get('_core')
+        self.__dict__.update(state)
+        if had_core is not None and '_core' in state:
+            from . import _lib
+            self.samples = _SampleList(self)
+            self._core = _lib.AmisCore(self.model.transitions, self.parameters[0][0], self.parameters[0][1],
+                                       self.brakes[0], self.brakes[1], self.logprior)
+            if had_core:
+                self._core.restore(self.parameters[1:], self._pool['ss'], self._pool['thetas'], self._arr_np)
+        elif 'samples' in state:
+            self.samples = _SampleList(self)
+
     @property
     def _arr(self):
         """ pooled per-sample arrays; with the native core they are fetched when somebody looks """

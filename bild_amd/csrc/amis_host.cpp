@@ -234,6 +234,47 @@ int bild_amis_pool(const bild_amis *m, int what, double *out)
     return BILD_OK;
 }
 
+// Rebuild a sampler from saved state (pickling / copying on the Python side): `Q_extra` further proposals after
+// the initial one, and the pooled samples with the per-sample arrays as bild_amis_pool returned them.
+int bild_amis_restore(bild_amis *m, int64_t Q_extra, const double *a, const double *logp, int64_t P, const double *ss,
+                      const int64_t *thetas, const double *logLs, const double *logd, const double *cur, const double *logw)
+{
+    if (!m || m->P() != 0 || m->a.size() != 1 || Q_extra < 0 || P < 0) return BILD_ERR_INVALID;
+    if ((Q_extra && (!a || !logp)) || (P && (!ss || !thetas || !logLs || !logd || !cur || !logw))) return BILD_ERR_INVALID;
+    const int k1 = m->k1, k = m->k, n = m->n;
+    for (int64_t q = 0; q < Q_extra; ++q) {
+        m->a.emplace_back(a + (size_t)q * k1, a + (size_t)(q + 1) * k1);
+        m->logp.emplace_back(logp + (size_t)q * n * k1, logp + (size_t)(q + 1) * n * k1);
+        m->derive(m->a.size() - 1);
+    }
+    m->ss.assign(ss, ss + (size_t)P * k1);
+    m->log_ss.resize((size_t)P * k1);
+    m->has_zero.resize(P);
+    m->first.resize(P);
+    m->pcode.resize((size_t)P * k);
+    m->theta.resize((size_t)P * k1);
+    for (int64_t p = 0; p < P; ++p) {
+        bool z = false;
+        for (int j = 0; j < k1; ++j) {
+            const double v = ss[(size_t)p * k1 + j];
+            z |= v == 0;
+            m->log_ss[(size_t)p * k1 + j] = v == 0 ? 0.0 : std::log(v);
+            const int64_t th = thetas[(size_t)p * k1 + j];
+            if (th < 0 || th >= n) return BILD_ERR_INVALID;
+            m->theta[(size_t)p * k1 + j] = (int32_t)th;
+        }
+        m->has_zero[p] = z;
+        m->first[p] = m->theta[(size_t)p * k1];
+        for (int i = 0; i < k; ++i)
+            m->pcode[(size_t)p * k + i] = (int32_t)((i * n + m->theta[(size_t)p * k1 + i]) * n + m->theta[(size_t)p * k1 + i + 1]);
+    }
+    m->logL.assign(logLs, logLs + P);
+    m->logd.assign(logd, logd + P);
+    m->cur.assign(cur, cur + P);
+    m->logw.assign(logw, logw + P);
+    return BILD_OK;
+}
+
 // State traces from the current proposal (amis.py:223-256): the caller supplies the uniform random numbers it
 // drew from the NumPy stream in the reference's order -- u[0..N) for the first slot (what np.random.choice
 // consumes), then one block of N per later slot (np.random.rand(N, 1)).

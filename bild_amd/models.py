@@ -140,6 +140,13 @@ class MultiStateRouse(MultiStateModel):
         self._trajsets = OrderedDict()
         return self
 
+    def __getstate__(self):
+        # device handles are not state: they are recreated on first use after unpickling / copying
+        state = dict(self.__dict__)
+        state['_handle'] = None
+        state['_trajsets'] = OrderedDict()
+        return state
+
     def arrays(self):
         """ stacked (B, G, Sig, M0, C0) over states, as the kernel consumes them (pyx:152-163) """
         if self.models is None:

@@ -201,6 +201,11 @@ int bild_amis_params(const bild_amis *m, int64_t which, double *a, double *logp)
 /* pooled per-sample arrays: 0 logLs, 1 log mixture denominators, 2 log density under the
  * current proposal, 3 log weights */
 int bild_amis_pool(const bild_amis *m, int what, double *out);
+/* rebuild a freshly created sampler from saved state: Q_extra further proposals (a: Q_extra x k1,
+ * logp: Q_extra x n x k1) and P pooled samples with their per-sample arrays */
+int bild_amis_restore(bild_amis *m, int64_t Q_extra, const double *a, const double *logp, int64_t P,
+                      const double *ss, const int64_t *thetas, const double *logLs,
+                      const double *logd, const double *cur, const double *logw);
 /* traces from the current proposal (amis.py:223-256); u: k1 blocks of N uniform numbers */
 int bild_amis_sample_traces(const bild_amis *m, int64_t N, const double *u, int64_t *thetas);
 /* one iteration: ss (N x k1), thetas (N x k1), logLs (N) -> evidence[3] = (logev, dlogev, KL);

@@ -211,3 +211,31 @@ def test_choice_counts_native_equals_numpy():
             Dn = cs.n0 - n_without
             Dn[omit] = 0
             assert np.isclose(cs.KLD_omitK(omit), 0.5 / cs.samplesize * np.sum(Dn ** 2 / (n_without + 1)), rtol=1e-13)
+
+
+def test_results_and_samplers_can_be_pickled_and_copied():
+    """ the reference's objects are plain Python and get pickled by users; native handles must not get in the way """
+    import copy
+    import pickle
+    from amis_cases import _table
+    tables = [_table(40, 2, 30, [8, 20])]
+    model = _SegmentTableModel(tables)
+    traj = bild_amd.Trajectory(np.zeros((30, 1)))
+    np.random.seed(2)
+    sampler = bild_amd.FixedkSampler(traj, model, k=2, N=20, max_fcomplete=0)
+    assert sampler.step() and sampler.step()
+    clones = [pickle.loads(pickle.dumps(sampler)), copy.deepcopy(sampler)]
+    state = np.random.get_state()
+    sampler.step()
+    for clone in clones:                                   # a clone continues exactly like the original
+        np.random.set_state(state)
+        clone.step()
+        assert np.allclose(clone.evidences, sampler.evidences, rtol=1e-13, atol=0)
+        assert np.array_equal(clone.samples[-1]['thetas'], sampler.samples[-1]['thetas'])
+        assert np.allclose(clone.samples[0]['log_weights'], sampler.samples[0]['log_weights'], rtol=0, atol=1e-12)
+    np.random.seed(3)
+    res = bild_amd.sample(traj, model, init_runs=2, k_max=3, sampler_kw={'N': 20, 'max_fev': 100}, choice_kw={'samplesize': 300})
+    back = pickle.loads(pickle.dumps(res))
+    assert np.array_equal(back.evidence, res.evidence) and back.best_k() == res.best_k()
+    assert np.array_equal(back.best_profile()[:], res.best_profile()[:])
+    assert np.allclose(back.log_marginal_posterior(), res.log_marginal_posterior(), rtol=0, atol=1e-12)

@@ -448,3 +448,19 @@ def test_extreme_shapes(built_lib, case):
                              H.expand(ss[pick], thetas[pick], T))
     # the running sums are ~60x longer than in the T = 1000 cases: the tolerance scales with T
     assert np.max(np.abs(got[pick] - want)) < TOL * max(1, T // 1000), case
+
+
+def test_model_survives_pickling_and_copying(built_lib):
+    """ device handles are dropped from the pickled state and recreated on first use """
+    import copy
+    import pickle
+    import bild_amd
+    rng = np.random.default_rng(8)
+    model = bild_amd.MultiStateRouse(20, 1, 5, d=3, localization_error=0.1)
+    traj = model.trajectory_from_loopingprofile(H.random_profile(rng, 150, 2, 40), rng=rng)
+    ss, thetas = H.candidate_profiles(rng, 33, 3, 2)
+    want = model.logL_st_batch(ss, thetas, traj)
+    for clone in (pickle.loads(pickle.dumps(model)), copy.deepcopy(model)):
+        assert clone._handle is None
+        assert np.array_equal(clone.logL_st_batch(ss, thetas, traj), want)
+    assert np.array_equal(model.logL_st_batch(ss, thetas, traj), want)      # the original is untouched
