@@ -333,6 +333,33 @@ class FactorizedModel(MultiStateModel):
         states = np.asarray(profile[:], dtype=int)
         return float(np.nansum(table[states, np.arange(len(states))]))
 
+    def trajectory_from_loopingprofile(self, profile, localization_error=0., missing_frames=None):
+        """
+        Generative model (reference bild/models.py:487-534): a distance from the state's distribution and a
+        uniformly random direction per frame.  The localization error is part of the distributions already: it is
+        only recorded on the trajectory, not added.
+        """
+        if np.isscalar(localization_error):
+            localization_error = self.d * [localization_error]
+        localization_error = np.asarray(localization_error, dtype=np.float64)
+        if localization_error.shape != (self.d,):
+            raise ValueError("Did not understand localization_error")
+        T = len(profile)
+        if missing_frames is None or (np.isscalar(missing_frames) and missing_frames == 0):
+            missing = np.array([], dtype=int)
+        elif np.isscalar(missing_frames):
+            if 0 < missing_frames < 1:
+                missing = np.nonzero(np.random.rand(T) < missing_frames)[0]
+            else:
+                missing = np.random.choice(T, size=missing_frames, replace=False).astype(int)
+        else:
+            missing = np.asarray(missing_frames, dtype=int)
+        magnitudes = np.array([self.distributions[state].rvs() for state in profile[:]])
+        data = np.random.normal(size=(len(magnitudes), self.d))
+        data *= np.expand_dims(magnitudes / np.linalg.norm(data, axis=1), 1)
+        data[missing, :] = np.nan
+        return Trajectory(data, localization_error=localization_error, loopingprofile=profile)
+
     def logL_batch(self, profiles, traj):
         table = self._table(traj)
         if not isinstance(profiles, np.ndarray):

@@ -70,3 +70,21 @@ def test_initial_loopingprofile_pins_of_the_reference():
     w = model.measurement
     for dist, C0 in zip(fact.distributions, model.arrays()['C0']):
         assert np.isclose(dist.kwds['scale'] ** 2, w @ C0 @ w + 0.25)
+
+
+def test_factorized_model_pins_of_the_reference():
+    """ reference tests/test_bild.py:175-195 """
+    import bild_amd
+    from scipy import stats
+    traj = bild_amd.Trajectory([1, 2, np.nan, 4], localization_error=[0.5])
+    profile = bild_amd.Loopingprofile([1, 1, 0, 0])
+    model = bild_amd.FactorizedModel([stats.maxwell(scale=1), stats.maxwell(scale=4)], d=1)
+    assert model.nStates == 2
+    for _ in range(2):
+        assert -100 < model.logL(profile, traj) < 0
+        assert np.array_equal(model.initial_loopingprofile(traj).state, [0, 0, 1, 1])
+        model.clear_memo()
+    gen = model.trajectory_from_loopingprofile(bild_amd.Loopingprofile([0, 0, 0, 1, 1, 1]))
+    assert len(gen) == 6 and gen[:].shape == (6, 1)
+    gen = model.trajectory_from_loopingprofile(bild_amd.Loopingprofile([0, 0, 0, 1, 1, 1]), missing_frames=[1, 4])
+    assert np.array_equal(np.isnan(gen[:][:, 0]), [False, True, False, False, True, False])
