@@ -77,3 +77,38 @@ def test_switch_indices_formula():
     ss = np.array([[0.25, 0.5, 0.25], [0.0, 0.0, 1.0], [1.0, 0.0, 0.0]])
     assert np.array_equal(switch_indices(ss, 6), [[2, 4], [1, 1], [6, 6]])
     assert switch_indices(np.ones((4, 1)), 10).shape == (4, 0)
+
+
+def test_loopingprofile_reference_fixture():
+    """ reference tests/test_bild.py:51-121 on its own fixture """
+    assert np.array_equal(Loopingprofile().state, np.array([]))
+    assert np.array_equal(Loopingprofile([1, 2, 3]).state, [1, 2, 3])
+    p = Loopingprofile([0, 0, 0, 1, 1, 0, 3, 3])
+    q = p.copy()
+    assert np.array_equal(q.state, p.state)
+    q[2] = 5
+    assert p[2] == 0                                                    # :61-65
+    assert len(p) == 8 and p[3] == 1 and np.array_equal(p[2:4], [0, 1])  # :67-73
+    p[2] = 3
+    assert p[2] == 3
+    try:
+        p[5] = 3.74
+        raise RuntimeError("float assignment must be rejected")         # :78-79
+    except AssertionError:
+        pass
+    assert p == Loopingprofile([0, 0, 3, 1, 1, 0, 3, 3]) and p != Loopingprofile([1, 0, 3])
+    p = Loopingprofile([0, 0, 0, 1, 1, 0, 3, 3])
+    assert p.count_switches() == 3                                      # :85-90
+    p[5] = 1
+    assert p.count_switches() == 2
+    p[4] = 2
+    assert p.count_switches() == 4
+    p = Loopingprofile([0, 0, 0, 1, 1, 0, 3, 3])
+    assert p.intervals() == [(None, 3, 0), (3, 5, 1), (5, 6, 0), (6, None, 3)]   # :92-102
+    assert Loopingprofile([1, 1, 1, 1]).intervals() == [(None, None, 1)]
+    t, y = p.plottable()                                                # :104-107
+    assert np.array_equal(t, [-1, 2, 2, 4, 4, 5, 5, 7]) and np.array_equal(y, [0, 0, 1, 1, 0, 0, 3, 3])
+    profs = [Loopingprofile([0, 1, 0, 1, 0]), Loopingprofile([1, 1, 1, 1, 1])]   # :109-121
+    assert np.array_equal(state_probabilities(profs), [[0.5, 0, 0.5, 0, 0.5], [0.5, 1, 0.5, 1, 0.5]])
+    assert np.array_equal(state_probabilities(profs, nStates=3),
+                          [[0.5, 0, 0.5, 0, 0.5], [0.5, 1, 0.5, 1, 0.5], [0, 0, 0, 0, 0]])
