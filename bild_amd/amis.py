@@ -435,7 +435,8 @@ class FixedkSampler:
         # time ('ss', 'thetas' and derived lookup data), `_arr` what an AMIS step recomputes for every sample
         # ('logLs', 'logδs', 'cur_log_proposal', 'log_weights'); `_sizes` the number of samples per step.
         self._sizes = []
-        self._pool = None
+        self._pool_np = None
+        self._chunks = []       # native path: (ss, thetas) per step, not yet appended to `_pool_np`
         self._arr_np = {}
         self._arr_cache = (None, None)
         self.samples = _SampleList(self)
@@ -460,6 +461,7 @@ class FixedkSampler:
 
     # -- pickling / copying: the native core is rebuilt from the pooled arrays ---------------------------
     def __getstate__(self):
+        self._pool                                    # append pending chunks
         state = dict(self.__dict__)
         if state.get('_core') is not None:
             state['_arr_np'] = dict(self._arr)
@@ -479,6 +481,20 @@ class FixedkSampler:
                 self._core.restore(self.parameters[1:], self._pool['ss'], self._pool['thetas'], self._arr_np)
         elif 'samples' in state:
             self.samples = _SampleList(self)
+
+    @property
+    def _pool(self):
+        """ pooled samples ('ss', 'thetas' [, lookup data of the NumPy path]); pending chunks are appended on access """
+        if self._chunks:
+            parts_ss = ([self._pool_np['ss']] if self._pool_np else []) + [c[0] for c in self._chunks]
+            parts_th = ([self._pool_np['thetas']] if self._pool_np else []) + [c[1] for c in self._chunks]
+            self._pool_np = {'ss': np.concatenate(parts_ss), 'thetas': np.concatenate(parts_th)}
+            self._chunks = []
+        return self._pool_np
+
+    @_pool.setter
+    def _pool(self, value):
+        self._pool_np = value
 
     @property
     def _arr(self):
@@ -687,11 +703,7 @@ class FixedkSampler:
         new_ss = self.dirichlet.sample(a_cur, self.N)
         new_thetas = self._core.sample_traces(np.random.random_sample((self.k + 1, self.N)))
         new_logLs = self.logL(new_ss, new_thetas)
-        if not self._sizes:
-            self._pool = {'ss': new_ss, 'thetas': new_thetas}
-        else:
-            self._pool = {'ss': np.concatenate([self._pool['ss'], new_ss]),
-                          'thetas': np.concatenate([self._pool['thetas'], new_thetas])}
+        self._chunks.append((new_ss, new_thetas))   # pooled on demand (`_pool`): a step itself does not need them
         self._sizes.append(len(new_ss))
         evidence = self._core.step(new_ss, new_thetas, new_logLs)    # RuntimeError if the CFC fit does not converge
         self.parameters.append(self._core.params(-1))

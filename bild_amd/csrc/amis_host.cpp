@@ -16,7 +16,9 @@
 #include <cstdint>
 #include <cstring>
 #include <limits>
+#include <cstdlib>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/bild_amd.h"
@@ -134,6 +136,39 @@ struct bild_amis {
 };
 
 namespace {
+
+// The passes over the pooled samples are cut into chunks of kChunk samples; every chunk produces its own partial
+// sums, which are then added in chunk order -- so the result does not depend on how many threads ran the chunks.
+// One thread by default: measured on the MI355X host at N = 10 000 (pool of 1e5 samples) 2-16 threads started per
+// pass were SLOWER (5.0-5.5 ms per AMIS step against 4.65 ms) -- the step is then dominated by drawing the samples
+// and by the likelihood, not by these passes.  BILD_AMIS_THREADS=<n> enables n threads for pools of >= 8 chunks.
+constexpr int64_t kChunk = 4096;
+
+int worker_count(int64_t nchunks)
+{
+    if (nchunks < 8) return 1;
+    int want = 1;
+    if (const char *e = getenv("BILD_AMIS_THREADS")) want = atoi(e);
+    return (int)std::max<int64_t>(1, std::min<int64_t>(want, nchunks / 2));
+}
+
+template <typename F>
+void for_chunks(int64_t P, F fn)
+{
+    const int64_t nchunks = (P + kChunk - 1) / kChunk;
+    const int workers = worker_count(nchunks);
+    auto run = [&](int w) {
+        for (int64_t c = w; c < nchunks; c += workers) fn(c, c * kChunk, std::min(P, (c + 1) * kChunk));
+    };
+    if (workers == 1) {
+        run(0);
+        return;
+    }
+    std::vector<std::thread> pool;
+    for (int w = 1; w < workers; ++w) pool.emplace_back(run, w);
+    run(0);
+    for (std::thread &t : pool) t.join();
+}
 
 // fixed-point inversion of one slot's marginals (amis.py:339-399): 0 ok, 1 did not converge
 int solve_marginals_single(const bild_amis &m, const double *logf, const double *logg, double *out)
@@ -333,12 +368,6 @@ int bild_amis_step(bild_amis *m, int64_t N, const double *ss, const int64_t *the
                 return BILD_ERR_INVALID;
             }
 
-    // 1. the mixture denominator of every earlier sample gains the current proposal
-    for (int64_t p = 0; p < P0; ++p) {
-        const double c = m->log_q(Q - 1, p);
-        m->cur[p] = c;
-        m->logd[p] = logaddexp(m->logd[p], c);
-    }
     // 2. the new samples and their own denominators: all proposals used so far
     const int64_t P = P0 + N;
     m->ss.insert(m->ss.end(), ss, ss + (size_t)N * k1);
@@ -351,70 +380,130 @@ int bild_amis_step(bild_amis *m, int64_t N, const double *ss, const int64_t *the
     m->logd.resize(P);
     m->cur.resize(P);
     m->logw.resize(P);
-    std::vector<double> lq(Q);
     for (int64_t r = 0; r < N; ++r) {
         const int64_t p = P0 + r;
         bool z = false;
         for (int j = 0; j < k1; ++j) {
-            const double s = ss[(size_t)r * k1 + j];
-            z |= s == 0;
-            m->log_ss[(size_t)p * k1 + j] = s == 0 ? 0.0 : std::log(s);
+            const double v = ss[(size_t)r * k1 + j];
+            z |= v == 0;
+            m->log_ss[(size_t)p * k1 + j] = v == 0 ? 0.0 : std::log(v);
         }
         m->has_zero[p] = z;
         m->first[p] = (int32_t)thetas[(size_t)r * k1];
         for (int i = 0; i < k1; ++i) m->theta[(size_t)p * k1 + i] = (int32_t)thetas[(size_t)r * k1 + i];
         for (int i = 0; i < k; ++i)
             m->pcode[(size_t)p * k + i] = (int32_t)((i * n + thetas[(size_t)r * k1 + i]) * n + thetas[(size_t)r * k1 + i + 1]);
-        for (size_t q = 0; q < Q; ++q) lq[q] = m->log_q(q, p);
-        m->cur[p] = lq[Q - 1];
-        m->logd[p] = lse((int)Q, lq.data(), 1, [](int) { return true; });
     }
-    // 3. deterministic-mixture weights: L / mean over proposals
+    const int64_t nchunks = (P + kChunk - 1) / kChunk;
     const double logQ = std::log((double)Q);
+    // pass A: 1. the mixture denominator of every earlier sample gains the current proposal; 2. the new samples'
+    // own denominators (all proposals used so far); 3. deterministic-mixture weights L / mean over proposals
+    std::vector<double> ctop(nchunks, -kInf);
+    std::vector<uint8_t> cnan(nchunks, 0);
+    for_chunks(P, [&](int64_t c, int64_t lo, int64_t hi) {
+        std::vector<double> lq(Q);
+        double top_c = -kInf;
+        bool nan_c = false;
+        for (int64_t p = lo; p < hi; ++p) {
+            if (p < P0) {
+                const double cq = m->log_q(Q - 1, p);
+                m->cur[p] = cq;
+                m->logd[p] = logaddexp(m->logd[p], cq);
+            } else {
+                for (size_t q = 0; q < Q; ++q) lq[q] = m->log_q(q, p);
+                m->cur[p] = lq[Q - 1];
+                m->logd[p] = lse((int)Q, lq.data(), 1, [](int) { return true; });
+            }
+            const double lw = m->logL[p] - m->logd[p] + logQ;
+            m->logw[p] = lw;
+            nan_c |= std::isnan(lw);
+            top_c = std::max(top_c, lw);
+        }
+        ctop[c] = top_c;
+        cnan[c] = nan_c;
+    });
     double top = -kInf;
     bool nan_w = false;
-    for (int64_t p = 0; p < P; ++p) {
-        m->logw[p] = m->logL[p] - m->logd[p] + logQ;
-        nan_w |= std::isnan(m->logw[p]);
-        top = std::max(top, m->logw[p]);
+    for (int64_t c = 0; c < nchunks; ++c) {
+        top = std::max(top, ctop[c]);
+        nan_w |= cnan[c] != 0;
     }
     if (nan_w) top = std::numeric_limits<double>::quiet_NaN(); // as np.max
 
     // ---- refit -------------------------------------------------------------------------------
-    // Dirichlet: weighted method of moments; weights below 1e-100 of the largest are dropped
-    std::vector<double> rel(P);
-    for (int64_t p = 0; p < P; ++p) {
-        const double dlt = m->logw[p] - top;
-        rel[p] = dlt < -746.0 ? 0.0 : std::exp(dlt); // exp underflows to exactly 0 below -745.2
+    // pass B: relative weights; first moments of the Dirichlet fit (weights below 1e-100 of the largest are
+    // dropped there), slot marginals of the CFC fit, sum of the weights for the evidence
+    const double tiny = std::numeric_limits<double>::min();
+    const int nm = n * k1;
+    std::vector<double> rel(P), cW(nchunks, 0.0), cS(nchunks, 0.0), cacc((size_t)nchunks * k1, 0.0), cmarg((size_t)nchunks * nm, 0.0);
+    const bool top_finite = std::isfinite(top);
+    for_chunks(P, [&](int64_t c, int64_t lo, int64_t hi) {
+        double *acc = cacc.data() + (size_t)c * k1, *mg = cmarg.data() + (size_t)c * nm;
+        double W = 0, S = 0;
+        for (int64_t p = lo; p < hi; ++p) {
+            const double dlt = m->logw[p] - top;
+            const double w = dlt < -746.0 ? 0.0 : std::exp(dlt); // exp underflows to exactly 0 below -745.2
+            rel[p] = w;
+            if (w >= 1e-100) {
+                W += w;
+                const double *sp = m->ss.data() + (size_t)p * k1;
+                for (int j = 0; j < k1; ++j) acc[j] += w * sp[j];
+            }
+            if (top_finite && w != 0) {
+                const int32_t *th = m->theta.data() + (size_t)p * k1;
+                for (int i = 0; i < k1; ++i) mg[(size_t)th[i] * k1 + i] += w;
+            }
+            if (w >= tiny) S += w; // subnormal weights: no effect on the sums
+        }
+        cW[c] = W;
+        cS[c] = S;
+    });
+    double W = 0, sum = 0;
+    std::vector<double> mean(k1, 0.0), marg(nm, 0.0);
+    for (int64_t c = 0; c < nchunks; ++c) {
+        W += cW[c];
+        sum += cS[c];
+        for (int j = 0; j < k1; ++j) mean[j] += cacc[(size_t)c * k1 + j];
+        for (int i = 0; i < nm; ++i) marg[i] += cmarg[(size_t)c * nm + i];
+    }
+    for (int j = 0; j < k1; ++j) mean[j] /= W;
+    const double ev = sum / (double)P;
+    // pass C: second moments of the Dirichlet fit; spread of the weights and the KL sum for the evidence block
+    std::vector<double> cvar((size_t)nchunks * k1, 0.0), csq(nchunks, 0.0), ckl(nchunks, 0.0);
+    for_chunks(P, [&](int64_t c, int64_t lo, int64_t hi) {
+        double *acc = cvar.data() + (size_t)c * k1;
+        double sq = 0, kl = 0;
+        for (int64_t p = lo; p < hi; ++p) {
+            const double w = rel[p];
+            if (w >= 1e-100) {
+                const double *sp = m->ss.data() + (size_t)p * k1;
+                for (int j = 0; j < k1; ++j) {
+                    const double dv = sp[j] - mean[j];
+                    acc[j] += w * dv * dv;
+                }
+            }
+            const double we = w < tiny ? 0.0 : w;
+            const double dv = we - ev;
+            sq += dv * dv;
+            const double term = we * (m->logL[p] - m->cur[p]);
+            if (!std::isnan(term)) kl += term; // zero-weight samples the current proposal cannot produce: dropped
+        }
+        csq[c] = sq;
+        ckl[c] = kl;
+    });
+    std::vector<double> var(k1, 0.0);
+    double sq = 0, kl = 0;
+    for (int64_t c = 0; c < nchunks; ++c) {
+        for (int j = 0; j < k1; ++j) var[j] += cvar[(size_t)c * k1 + j];
+        sq += csq[c];
+        kl += ckl[c];
     }
     std::vector<double> new_a(k1);
     {
-        double W = 0;
-        for (int64_t p = 0; p < P; ++p)
-            if (rel[p] >= 1e-100) W += rel[p];
-        std::vector<double> acc(k1, 0.0);
-        for (int64_t p = 0; p < P; ++p)
-            if (rel[p] >= 1e-100) {
-                const double w = rel[p];
-                const double *s = m->ss.data() + (size_t)p * k1;
-                for (int j = 0; j < k1; ++j) acc[j] += (double)w * s[j];
-            }
-        std::vector<double> mean(k1), var(k1);
-        for (int j = 0; j < k1; ++j) mean[j] = (double)(acc[j] / W);
-        std::fill(acc.begin(), acc.end(), 0.0);
-        for (int64_t p = 0; p < P; ++p)
-            if (rel[p] >= 1e-100) {
-                const double w = rel[p];
-                const double *s = m->ss.data() + (size_t)p * k1;
-                for (int j = 0; j < k1; ++j) {
-                    const double dv = s[j] - mean[j];
-                    acc[j] += (double)w * dv * dv;
-                }
-            }
         bool degenerate = false;
         double tot = 0;
         for (int j = 0; j < k1; ++j) {
-            var[j] = (double)(acc[j] / W);
+            var[j] /= W;
             degenerate |= var[j] == 0;
         }
         if (degenerate) {
@@ -428,15 +517,6 @@ int bild_amis_step(bild_amis *m, int64_t N, const double *ss, const int64_t *the
     // CFC: weighted slot marginals -> weights
     std::vector<double> new_logp((size_t)n * k1);
     {
-        std::vector<double> marg((size_t)n * k1, 0.0);
-        if (std::isfinite(top)) {
-            for (int64_t p = 0; p < P; ++p) {
-                const double w = rel[p];
-                if (w == 0) continue;
-                const int32_t *th = m->theta.data() + (size_t)p * k1;
-                for (int i = 0; i < k1; ++i) marg[(size_t)th[i] * k1 + i] += w;
-            }
-        }
         std::vector<double> lm((size_t)n * k1);
         for (size_t i = 0; i < lm.size(); ++i) lm[i] = std::log((double)marg[i]) + top;
         for (int i = 0; i < k1; ++i) {
@@ -494,25 +574,11 @@ int bild_amis_step(bild_amis *m, int64_t N, const double *ss, const int64_t *the
 
     // ---- evidence, its standard error, KL(posterior || current proposal) (amis.py:876-903) ---------
     {
-        const double tiny = std::numeric_limits<double>::min();
-        double sum = 0;
-        for (int64_t p = 0; p < P; ++p) {
-            if (rel[p] < tiny) rel[p] = 0; // subnormal weights: no effect on the sums
-            sum += rel[p];
-        }
-        const double ev = (double)(sum / P);
-        double sq = 0, kl = 0;
-        for (int64_t p = 0; p < P; ++p) {
-            const double dv = rel[p] - ev;
-            sq += (double)dv * dv;
-            const double term = rel[p] * (m->logL[p] - m->cur[p]);
-            if (!std::isnan(term)) kl += term; // zero-weight samples the current proposal cannot produce: dropped
-        }
         const double logev = std::log(ev) + top + m->logprior;
-        const double sd = P > 1 ? std::sqrt((double)(sq / (P - 1))) : std::numeric_limits<double>::quiet_NaN();
+        const double sd = P > 1 ? std::sqrt(sq / (double)(P - 1)) : std::numeric_limits<double>::quiet_NaN();
         evidence[0] = logev;
         evidence[1] = sd / std::sqrt((double)P) / ev;
-        evidence[2] = (double)(kl / P) / ev - logev + m->logprior;
+        evidence[2] = kl / (double)P / ev - logev + m->logprior;
     }
     m->steps += 1;
     m->err.clear();
