@@ -5,12 +5,14 @@ Counterpart of reference bild/amis.py: the proposa
 (`Dirichlet` over switch intervals, `CFC` over state traces) and the `FixedkSampler` whose
 ``logL(ss, thetas)`` is the batch boundary of the GPU likelihood (bild/amis.py:717-739).
 
-Everything here except ``FixedkSampler.logL`` is cheap host-side O(N k) bookkeeping and stays
-in NumPy.  Behaviour follows the reference function by function (citations in the
-docstrings); the random streams are consumed in the same order (``scipy.stats.dirichlet.rvs``,
-``np.random.choice``, ``np.random.rand``), so that with the same ``np.random.seed`` and the
-same likelihood values a sampler of this module and a reference sampler walk through
-identical proposals, weights and evidences (tests/test_amis_parity.py).
+Everything here except ``FixedkSampler.logL`` is host-side O(N k) bookkeeping.  Behaviour follows the
+reference function by function (citations in the docstrings); the random streams are consumed in the
+same order (``np.random.dirichlet`` as ``scipy.stats.dirichlet.rvs`` calls it, ``np.random.choice``,
+``np.random.rand``), so that with the same ``np.random.seed`` and the same likelihood values a sampler
+of this module and a reference sampler walk through identical proposals, weights and evidences
+(tests/test_amis.py, against runs of the reference stored in tests/golden/amis_*.npz).  The per-step
+bookkeeping of `FixedkSampler` exists twice: in NumPy here (the specification) and as native host code
+behind the C ABI (csrc/amis_host.cpp, the default).
 
 Profiles are parametrised as ``(s, theta)``: ``s`` (k+1,) interval lengths on the unit
 simplex, ``theta`` (k+1,) the state of each interval; neighbouring states obey the model's
