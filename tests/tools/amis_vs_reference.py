@@ -4,10 +4,10 @@ Host-side cost of one AMIS step, proposal bookkeeping only (likelihood time subt
 bild/amis.py (imported through oracle/ref_loader.py -- build container only) against bild_amd.amis, same seed,
 same table likelihood, T = 1000, k = 4.  Also checks that both walk through the same evidences.
 
-    python tools/amis_vs_reference.py [N] [steps]
+    python tests/tools/amis_vs_reference.py [N] [steps]
 """
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 os.environ.setdefault('PYTHONDONTWRITEBYTECODE', '1')
 import numpy as np

@@ -5,14 +5,14 @@ reference's Python loop (amis.py:735-739) over its own shard of the bench batch 
 for a fixed time.  Kernels: the reference's Cython MSRouse_logL built unmodified into oracle/_ref ("reference"),
 and this repository's C restatement of it ("port", oracle/msrouse_logl.c).  CPU only -- nothing here touches a GPU.
 
-    python tools/cpu_allcores.py [processes] [seconds]
+    python tests/tools/cpu_allcores.py [processes] [seconds]
 """
 import multiprocessing as mp
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def worker(rank, world, kind, seconds, out):

@@ -2,10 +2,10 @@
 Throughput and parity by spatial dimension / localization-error pattern (which decides how many mean vectors a
 covariance chain carries, hence the lanes per task): 10 000 x T = 1000, 2-state N = 20, modal path.
 
-    python tools/dims_check.py [N]
+    python tests/tools/dims_check.py [N]
 """
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, helpers as H, bild_amd
 from bild_amd import _lib

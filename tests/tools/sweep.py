@@ -4,7 +4,7 @@ Chain-length / localization-error sweep of SURVEY.md section 8d: N in {4, 8, 16,
 10 000 candidate profiles x T = 1000, 2-state, k = 4 on one GPU; beside each the reference Cython kernel
 (oracle/_ref) on one host core over a few seconds, and the max |delta logL| between the two on that sample.
 
-    python tools/sweep.py > profiles/r01_sweep.txt          # on the GPU box
+    python tests/tools/sweep.py > profiles/r01_sweep.txt          # on the GPU box
 """
 import os
 import sys
@@ -12,7 +12,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
