@@ -67,6 +67,7 @@ _SIGNATURES = {
     'bild_amis_restore': (ctypes.c_int, [_vp, ctypes.c_int64, _dp, _dp, ctypes.c_int64, _dp, _vp, _dp, _dp, _dp, _dp]),
     'bild_amis_sample_traces': (ctypes.c_int, [_vp, ctypes.c_int64, _dp, _vp]),
     'bild_amis_step': (ctypes.c_int, [_vp, ctypes.c_int64, _dp, _vp, _dp, _dp]),
+    'bild_interval_marginals': (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int64, _ip, _ip, _dp, _dp]),
     'bild_choice_counts': (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, _dp, _dp, _dp, ctypes.c_double, _vp, _vp, _vp, _vp]),
 }
 
@@ -322,3 +323,14 @@ def choice_counts(rvs, mu, dmu, dE, omit=None, want_dn=True):
     if code != OK:
         raise BildAmdError(code, "bild_choice_counts failed")
     return n0, dn, n_omit
+
+
+def interval_marginals(seg_start, seg_state, w, n, T):
+    """ (n, T) weighted state occupancy per frame of the profiles (seg_start, seg_state) with weights w """
+    seg_start, seg_state, w = i32(seg_start), i32(seg_state), f64(w)
+    P, k1 = seg_state.shape
+    post = np.empty((n, T), dtype=np.float64)
+    code = lib().bild_interval_marginals(P, k1, n, T, iptr(seg_start), iptr(seg_state), dptr(w), dptr(post))
+    if code != OK:
+        raise BildAmdError(code, "bild_interval_marginals failed")
+    return post

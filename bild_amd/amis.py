@@ -24,7 +24,7 @@ import math
 import numpy as np
 from scipy.special import gammaln, xlogy
 
-from .profiles import Loopingprofile, switch_indices
+from .profiles import Loopingprofile, segments_from_st, switch_indices
 
 
 # ----------------------------------------------------------------------------------------
@@ -726,13 +726,15 @@ class FixedkSampler:
         j = int(np.argmax(self._arr['logLs']))   # first occurrence of the maximum, as the reference's nested argmax
         return self.st2profile(self._pool['ss'][j], self._pool['thetas'][j])
 
-    def log_marginal_posterior(self):
+    def log_marginal_posterior(self, native=True):
         """
         (n, T) normalised log posterior marginals of the state at each frame (bild/amis.py:945-972).
 
-        Samples are expanded to frames in vectorised chunks (one pass per interval) and their weights
-        summed per state -- sums of non-negative terms only, like the reference's logsumexp, so that
-        tiny marginals keep their relative accuracy.
+        Per frame and state the weights of the samples whose profile is in that state are summed -- sums of
+        non-negative terms only, like the reference's logsumexp, so that tiny marginals keep their relative
+        accuracy.  ``native=True``: every interval of every sample goes into a range-add tree (O(P k log T),
+        csrc/amis_host.cpp); ``native=False``: the samples are expanded to frames in vectorised NumPy chunks
+        (O(P T): seconds for a finished sampler; kept as the specification).
         """
         pooled = dict(self._arr, ss=self._pool['ss'], thetas=self._pool['thetas'])
         log_weights = pooled['log_weights'] if 'log_weights' in pooled else pooled['logLs']
@@ -740,20 +742,25 @@ class FixedkSampler:
         n = self.model.nStates
         thetas = np.asarray(pooled['thetas'])
         k1 = thetas.shape[1]
-        starts = switch_indices(pooled['ss'], T) if k1 > 1 else np.zeros((len(thetas), 0), dtype=np.int32)
         top = np.max(log_weights)
         with np.errstate(under='ignore'):
             w = np.exp(log_weights - top)
-        frames = np.arange(T)[None, :]
-        post = np.zeros((n, T))
-        chunk = max(1, (1 << 22) // max(T, 1))
-        for lo in range(0, len(thetas), chunk):
-            hi = min(lo + chunk, len(thetas))
-            states = np.repeat(thetas[lo:hi, :1], T, axis=1)
-            for i in range(1, k1):                                   # later intervals overwrite, as st2profile does
-                states = np.where(frames >= starts[lo:hi, i - 1:i], thetas[lo:hi, i:i + 1], states)
-            for st in range(n):
-                post[st] += w[lo:hi] @ (states == st)
+        if native:
+            from . import _lib
+            seg_start, seg_state = segments_from_st(pooled['ss'], thetas, T)
+            post = _lib.interval_marginals(seg_start, seg_state, w, n, T)
+        else:
+            starts = switch_indices(pooled['ss'], T) if k1 > 1 else np.zeros((len(thetas), 0), dtype=np.int32)
+            frames = np.arange(T)[None, :]
+            post = np.zeros((n, T))
+            chunk = max(1, (1 << 22) // max(T, 1))
+            for lo in range(0, len(thetas), chunk):
+                hi = min(lo + chunk, len(thetas))
+                states = np.repeat(thetas[lo:hi, :1], T, axis=1)
+                for i in range(1, k1):                                   # later intervals overwrite, as st2profile does
+                    states = np.where(frames >= starts[lo:hi, i - 1:i], thetas[lo:hi, i:i + 1], states)
+                for st in range(n):
+                    post[st] += w[lo:hi] @ (states == st)
         with np.errstate(divide='ignore', under='ignore'):
             logpost = np.log(post) + top
             return logpost - logsumexp(logpost, axis=0)

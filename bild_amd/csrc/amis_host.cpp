@@ -636,4 +636,44 @@ int bild_choice_counts(int64_t samplesize, int kmax, const double *rvs, const do
     return BILD_OK;
 }
 
+// Weighted state occupancy per frame (reference bild/amis.py:945-972 sums, per frame, the weights of the samples
+// whose profile is in each state): post[s][t] = sum of w[p] over samples p whose interval covering frame t has
+// state s.  Profiles are given as in bild_logl_segments (seg_start / seg_state, P x k1, seg_start[p][0] = 0,
+// non-decreasing).  Every interval is added to O(log T) nodes of a range-add tree and a frame's value is the sum
+// of the O(log T) nodes above it: only non-negative terms are ever added, so tiny marginals keep their relative
+// accuracy (a difference array would not), at O(P k1 log T + n T log T) instead of O(P T) operations.
+int bild_interval_marginals(int64_t P, int k1, int n, int64_t T, const int32_t *seg_start, const int32_t *seg_state,
+                            const double *w, double *post)
+{
+    if (P < 0 || k1 < 1 || n < 1 || T < 1 || !post || (P && (!seg_start || !seg_state || !w))) return BILD_ERR_INVALID;
+    int64_t T2 = 1;
+    while (T2 < T) T2 <<= 1;
+    std::vector<double> tree((size_t)n * 2 * T2, 0.0);
+    for (int64_t p = 0; p < P; ++p) {
+        const double wp = w[p];
+        if (!(wp > 0)) continue;
+        for (int i = 0; i < k1; ++i) {
+            const int st = seg_state[(size_t)p * k1 + i];
+            if (st < 0 || st >= n) return BILD_ERR_INVALID;
+            int64_t lo = std::min<int64_t>(seg_start[(size_t)p * k1 + i], T);
+            int64_t hi = i + 1 < k1 ? std::min<int64_t>(seg_start[(size_t)p * k1 + i + 1], T) : T;
+            if (lo < 0 || hi <= lo) continue;
+            double *tr = tree.data() + (size_t)st * 2 * T2;
+            for (lo += T2, hi += T2; lo < hi; lo >>= 1, hi >>= 1) {
+                if (lo & 1) tr[lo++] += wp;
+                if (hi & 1) tr[--hi] += wp;
+            }
+        }
+    }
+    for (int st = 0; st < n; ++st) {
+        const double *tr = tree.data() + (size_t)st * 2 * T2;
+        for (int64_t t = 0; t < T; ++t) {
+            double acc = 0;
+            for (int64_t node = t + T2; node >= 1; node >>= 1) acc += tr[node];
+            post[(size_t)st * T + t] = acc;
+        }
+    }
+    return BILD_OK;
+}
+
 } // extern "C"

@@ -222,6 +222,12 @@ int bild_choice_counts(int64_t samplesize, int kmax, const double *rvs, const do
                        const double *dmu, double dE, const uint8_t *omit,
                        int64_t *n0, int64_t *dn, int64_t *n_omit);
 
+/* Weighted state occupancy per frame over a set of profiles (reference bild/amis.py:945-972):
+ * post[s*T + t] = sum of w[p] over the profiles p that are in state s at frame t.  Profiles as
+ * in bild_logl_segments (P x k1).  Sums of non-negative terms only. */
+int bild_interval_marginals(int64_t P, int k1, int n, int64_t T, const int32_t *seg_start,
+                            const int32_t *seg_state, const double *w, double *post);
+
 #ifdef __cplusplus
 }
 #endif
