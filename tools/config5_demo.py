@@ -41,3 +41,21 @@ for name, runner in (('sequential sample()', lambda: [bild_amd.sample(t, model, 
     ks = [int(r.best_k()) for r in res]
     print(f"{name}: {dt:7.2f} s wall, {steps} AMIS steps, {evals} likelihood evaluations, {launches} kernel launches "
           f"({kms:.0f} ms on the GPU), best k histogram {np.bincount(ks).tolist()}")
+    if name.startswith('fused'):
+        # what a user does with the results: posterior marginals, best profile, boundary polishing
+        from bild_amd import postproc
+        t0 = time.perf_counter()
+        posts = [r.log_marginal_posterior() for r in res]
+        t1 = time.perf_counter()
+        best = [r.best_profile() for r in res]
+        t2 = time.perf_counter()
+        polished = []
+        for r, prof in zip(res, best):
+            try:
+                polished.append(postproc.optimize_boundary(prof, r.traj, model))
+            except postproc.BoundaryEliminationError:
+                polished.append(prof)
+        t3 = time.perf_counter()
+        moved = sum(int(np.sum(a[:] != b[:])) for a, b in zip(best, polished))
+        print(f"post-processing of {len(res)} results: log_marginal_posterior {t1 - t0:.2f} s, best_profile {t2 - t1:.3f} s, "
+              f"optimize_boundary {t3 - t2:.2f} s ({moved} frames moved)")
