@@ -5,7 +5,7 @@
 // eigenbasis of the current state's propagator, a state switch is the basis change  A <- R A,
 // C <- C R^T  (reference bild/src/MSRouse_logL.pyx:186-256 in that basis; see kernels.hip).
 //
-// Mapping: ONE task per workgroup of 256 lanes; the filter state A = [C | M] (NP x (NP + 3)) lives in
+// Mapping: ONE task per workgroup of 256-1024 lanes (by chain length); the filter state A = [C | M] (NP x (NP + 3)) lives in
 // LDS, column-major with an odd leading dimension (conflict-free both along a column and across
 // columns).  A lane owns a fixed (column, row slice) of A for the whole recursion, so the per-frame
 // passes over A need no synchronisation among themselves; the cross-lane steps of a frame are the
@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <limits.h>
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -28,8 +29,8 @@ namespace {
 
 constexpr double kLog2Pi = 1.8378770664093453;
 constexpr double kLn2 = 0.69314718055994531;
-constexpr int kThreads = 256;
 
+template <int kThreads>
 __global__ void __launch_bounds__(kThreads) logl_wide_kernel(const KParams p, const int NP)
 {
     extern __shared__ __align__(16) double sm[];
@@ -227,20 +228,38 @@ __global__ void __launch_bounds__(kThreads) logl_wide_kernel(const KParams p, co
 
 } // namespace
 
+// lanes per workgroup, by chain length: more lanes shorten a lane's row slice but make the three barriers of a
+// frame dearer.  Measured on 5 000-10 000 x T = 1000 batches (profiles/r01_wide.txt): 256 lanes win up to n = 64,
+// 512 for n = 72 ... 88, 1024 from n = 100 (2.4x / 3.5x faster than 256 at n = 100 / 128).
+// env BILD_WIDE_THREADS overrides (256 / 512 / 1024).
+int wide_threads(int NP)
+{
+    if (const char *e = getenv("BILD_WIDE_THREADS")) {
+        const int t = atoi(e);
+        if (t == 256 || t == 512 || t == 1024) return t;
+    }
+    return NP <= 68 ? 256 : (NP <= 92 ? 512 : 1024);
+}
+
 size_t wide_lds_bytes(int NP)
 {
-    const int NC = NP + kDMax, LD = NP + 1, R = kThreads / NC;
+    const int NC = NP + kDMax, LD = NP + 1, R = wide_threads(NP) / NC;
     return ((size_t)NC * LD + 3 * (size_t)NP + NC + (size_t)R * NC + 4) * sizeof(double);
 }
 
 int launch_logl_wide(int NP, const KParams &p, int grid, void *stream)
 {
     const size_t lds = wide_lds_bytes(NP);
-    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(logl_wide_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (err != hipSuccess) return (int)err;
-    hipLaunchKernelGGL(logl_wide_kernel, dim3(grid), dim3(kThreads), lds, reinterpret_cast<hipStream_t>(stream), p, NP);
-    return (int)hipGetLastError();
+    const int threads = wide_threads(NP);
+    auto go = [&](auto kernel) -> int {
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err != hipSuccess) return (int)err;
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, reinterpret_cast<hipStream_t>(stream), p, NP);
+        return (int)hipGetLastError();
+    };
+    if (threads == 1024) return go(logl_wide_kernel<1024>);
+    if (threads == 512) return go(logl_wide_kernel<512>);
+    return go(logl_wide_kernel<256>);
 }
 
 } // namespace bild
