@@ -122,7 +122,13 @@ def sample_many(trajs, model, **kwargs):
     a trajectory whose loop raised gets the exception object as its entry instead of aborting the rest.
     """
     from .batching import run_batched
-    return run_batched(trajs, model, sample, **kwargs)
+    results = run_batched(trajs, model, sample, **kwargs)
+    for res in results:     # the loops saw a batching proxy of the model: hand the real one back
+        if isinstance(res, SamplingResults):
+            res.model = model
+            for sampler in res.samplers:
+                sampler.model = model
+    return results
 
 
 class _NoBar:

@@ -112,3 +112,58 @@ class ShardedModel:
             device = 'cuda' if dist.get_backend(self._group) == 'nccl' else 'cpu'
         full = all_gather_logl_ragged(torch.from_numpy(local).to(device), [b - a for a, b in bounds], self._group)
         return full.cpu().numpy()
+
+
+def sample_many_distributed(trajs, model, group=None, seed=None, gather='all', **kwargs):
+    """
+    `core.sample_many` over all ranks of a process group: whole trajectories are assigned to ranks
+    (`shard_by_trajectory`, cost ~ length), every rank runs the fused inference of its own trajectories on its
+    own GPU -- likelihood launches AND host-side sampler bookkeeping scale with the number of ranks, there is no
+    communication while sampling -- and the results (plain picklable objects) are exchanged once at the end.
+
+    gather : 'all' -- every rank returns the full list, in the order of ``trajs`` (``all_gather_object``; the
+             results carry all samples drawn, ~100 bytes per sample: mind the size for thousands of trajectories);
+             'root' -- only rank 0 does, the others get ``None`` in place of foreign results (``gather_object``);
+             None -- no exchange: foreign entries are ``None``.
+    seed : rank r seeds the global NumPy stream with ``seed + r`` first (the trajectories a rank gets depend on
+           the number of ranks, so a run is reproducible for a fixed world size).
+
+    Without ``torch.distributed`` initialised this is `core.sample_many`.
+    """
+    from .core import sample_many
+    trajs = list(trajs)
+    try:
+        import torch.distributed as dist
+        active = dist.is_available() and dist.is_initialized()
+    except ImportError:  # pragma: no cover
+        active = False
+    if not active:
+        if seed is not None:
+            np.random.seed(seed)
+        return sample_many(trajs, model, **kwargs)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    owners = shard_by_trajectory([len(t) for t in trajs], np.ones(len(trajs)), world)
+    if seed is not None:
+        np.random.seed(seed + rank)
+    mine = owners[rank]
+    local = sample_many([trajs[j] for j in mine], model, **kwargs) if len(mine) else []
+    out = [None] * len(trajs)
+    for j, r in zip(mine.tolist(), local):
+        out[j] = r
+    if gather is None:
+        return out
+    payload = (mine.tolist(), local)
+    if gather == 'all':
+        gathered = [None] * world
+        dist.all_gather_object(gathered, payload, group=group)
+    elif gather == 'root':
+        gathered = [None] * world if rank == 0 else None
+        dist.gather_object(payload, gathered, dst=0, group=group)
+        if rank != 0:
+            return out
+    else:
+        raise ValueError("gather must be 'all', 'root' or None")
+    for idx, res in gathered:
+        for j, r in zip(idx, res):
+            out[j] = r
+    return out

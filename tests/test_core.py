@@ -235,6 +235,9 @@ def test_results_and_samplers_can_be_pickled_and_copied():
         assert np.allclose(clone.samples[0]['log_weights'], sampler.samples[0]['log_weights'], rtol=0, atol=1e-12)
     np.random.seed(3)
     res = bild_amd.sample(traj, model, init_runs=2, k_max=3, sampler_kw={'N': 20, 'max_fev': 100}, choice_kw={'samplesize': 300})
+    fused = bild_amd.sample_many([traj], model, init_runs=2, k_max=3, sampler_kw={'N': 20, 'max_fev': 100}, choice_kw={'samplesize': 300})
+    assert fused[0].model is model and all(smp.model is model for smp in fused[0].samplers)   # no batching proxy left behind
+    pickle.dumps(fused)
     back = pickle.loads(pickle.dumps(res))
     assert np.array_equal(back.evidence, res.evidence) and back.best_k() == res.best_k()
     assert np.array_equal(back.best_profile()[:], res.best_profile()[:])

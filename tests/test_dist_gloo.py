@@ -121,6 +121,50 @@ def test_replicated_amis_with_sharded_likelihood_world2():
     assert np.array_equal(np.concatenate([s['logLs'] for s in ref.samples]), l0)
 
 
+def _routed_model(tables):
+    from test_core import _SegmentTableModel
+
+    class Routed(_SegmentTableModel):      # the fused evaluator sees local trajectory ids: route by the trajectory itself
+        def logL_segments(self, seg_start, seg_state, trajs_, traj_id):
+            ids = np.array([int(trajs_[j][0, 0]) for j in traj_id])
+            return super().logL_segments(seg_start, seg_state, None, ids)
+
+        def __reduce__(self):              # results carry their model: make this test double picklable
+            return (_routed_model, (self.tables,))
+    return Routed(tables)
+
+
+def _many_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import bild_amd
+    from bild_amd.dist import sample_many_distributed
+    from amis_cases import _table
+    from test_core import _SegmentTableModel
+    tables = [_table(50 + j, 2, 14 + 5 * j, [4 + j, 9 + 2 * j]) for j in range(5)]
+    trajs = [bild_amd.Trajectory(np.full((t.shape[1], 1), float(j))) for j, t in enumerate(tables)]
+
+    res = sample_many_distributed(trajs, _routed_model(tables), seed=5, init_runs=2, k_max=3,
+                                  sampler_kw={'N': 20, 'max_fev': 200, 'max_fcomplete': 30}, choice_kw={'samplesize': 300})
+    ret[rank] = [(len(r.traj), r.best_k(), np.array(r.evidence), r.best_profile()[:]) for r in res]
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sample_many_distributed_world2():
+    """ trajectories sharded over 2 ranks, one object all-gather at the end: every rank holds every result, in order """
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_many_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+        r0, r1 = ret[0], ret[1]
+    assert [x[0] for x in r0] == [14, 19, 24, 29, 34]                    # all five results, in the order of the input
+    for a, b in zip(r0, r1):
+        assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2], equal_nan=True) and np.array_equal(a[3], b[3])
+        assert len(a[3]) == a[0] and np.all(np.isfinite(a[2][:2]))
+
+
 _RCCL_SCRIPT = r'''
 import os, sys
 import numpy as np, torch, torch.distributed as dist
