@@ -140,6 +140,24 @@ class MultiStateRouse(MultiStateModel):
         self._trajsets = OrderedDict()
         return self
 
+    @classmethod
+    def from_reference(cls, ref_model, path='auto'):
+        """
+        Build from a reference ``bild.models.MultiStateRouse`` (or anything with its attribute surface:
+        ``models[i]._dynamics['B'|'G'|'Sig']``, ``.check_dynamics()``, ``.steady_state()``, ``measurement``,
+        ``localization_error``; reference bild/src/MSRouse_logL.pyx:150-160): the matrices of the installed
+        ``rouse`` package are used as they are, bypassing this package's own Rouse builder.
+        """
+        for mod in ref_model.models:
+            mod.check_dynamics()
+        steady = [mod.steady_state() for mod in ref_model.models]
+        return cls.from_arrays(B=np.array([mod._dynamics['B'] for mod in ref_model.models]),
+                               G=np.array([mod._dynamics['G'] for mod in ref_model.models]),
+                               Sig=np.array([mod._dynamics['Sig'] for mod in ref_model.models]),
+                               M0=np.array([st[0] for st in steady]), C0=np.array([st[1] for st in steady]),
+                               measurement=ref_model.measurement,
+                               localization_error=getattr(ref_model, 'localization_error', None), path=path)
+
     def __getstate__(self):
         # device handles are not state: they are recreated on first use after unpickling / copying
         state = dict(self.__dict__)

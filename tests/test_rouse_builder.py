@@ -88,3 +88,18 @@ def test_factorized_model_pins_of_the_reference():
     assert len(gen) == 6 and gen[:].shape == (6, 1)
     gen = model.trajectory_from_loopingprofile(bild_amd.Loopingprofile([0, 0, 0, 1, 1, 1]), missing_frames=[1, 4])
     assert np.array_equal(np.isnan(gen[:][:, 0]), [False, True, False, False, True, False])
+
+
+def test_from_reference_takes_the_matrices_as_they_are():
+    """ `MultiStateRouse.from_reference` on the attribute surface the reference kernel reads (pyx:150-160) """
+    import bild_amd
+    import helpers as H
+    duck = H.DuckModel(N=12, D=1., k=3., d=2, localization_error=[0.1, 0.2])
+    model = bild_amd.MultiStateRouse.from_reference(duck)
+    want = duck.arrays()
+    got = model.arrays()
+    for key in ('B', 'G', 'Sig', 'M0', 'C0'):
+        assert np.array_equal(np.asarray(got[key]), np.asarray(want[key])), key
+    assert np.array_equal(model.measurement, duck.measurement) and model.nStates == 2 and model.d == 2
+    assert np.array_equal(model.localization_error, [0.1, 0.2])
+    assert np.array_equal(model.initial_loopingprofile(bild_amd.Trajectory(np.array([[0.1, 0.1], [3., 2.]])))[:].shape, (2,))
