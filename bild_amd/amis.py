@@ -152,7 +152,12 @@ class Dirichlet:
             total = 1e10  # degenerate sample: very concentrated but finite, the brake takes over
         else:
             total = np.mean(m * (1 - m) / v) - 1
-        return total * m
+        # Weight on the boundary of the simplex (a proposal that has collapsed there: m_i = 1 up to rounding, or
+        # m_i = 0) makes the formula return a negative / zero / non-finite concentration, with which the reference
+        # ends in ValueError("alpha <= 0").  Treated like the degenerate case above; components stay positive.
+        if not (np.isfinite(total) and total > 0):
+            total = 1e10
+        return np.maximum(total * m, np.finfo(np.float64).tiny)
 
 
 # ----------------------------------------------------------------------------------------
@@ -526,8 +531,13 @@ class FixedkSampler:
 
     # -- densities --------------------------------------------------------------------------
     def log_proposal(self, parameters, ss, thetas):
-        """ log density of the product proposal (bild/amis.py:697-715) """
-        return self.dirichlet.logpdf(parameters[0], ss) + self.cfc.logpmf(parameters[1], thetas)
+        """
+        log density of the product proposal (bild/amis.py:697-715); zero where the trace has probability zero,
+        also at a pole of the Dirichlet factor (see `step`)
+        """
+        cont, disc = self.dirichlet.logpdf(parameters[0], ss), self.cfc.logpmf(parameters[1], thetas)
+        with np.errstate(invalid='ignore'):
+            return np.where(disc == -np.inf, -np.inf, cont + disc)
 
     def logL(self, ss, thetas):
         """
@@ -612,8 +622,14 @@ class FixedkSampler:
 
         def log_proposals(which, pool):
             """ (len(which), N) log densities of the proposals ``which`` at the samples of ``pool`` """
-            return (self.dirichlet.logpdf_many(self._As[which], pool['ss'], pool['log_ss'])
-                    + self.cfc.logpmf_many(None, None, pool['codes'], (self._heads[which], self._tables[which])))
+            cont = self.dirichlet.logpdf_many(self._As[which], pool['ss'], pool['log_ss'])
+            disc = self.cfc.logpmf_many(None, None, pool['codes'], (self._heads[which], self._tables[which]))
+            with np.errstate(invalid='ignore'):
+                both = cont + disc
+            # a trace of probability zero has proposal density zero, also at a pole of the Dirichlet factor (s_i = 0
+            # where a_i < 1: the reference adds +inf and -inf to NaN there, which ends in "Iteration did not converge";
+            # proposals that collapse onto the boundary of the simplex, a_i ~ 1e-16, produce such samples in numbers)
+            return np.where(disc == -np.inf, -np.inf, both)
 
         pool, arr = self._pool, self._arr
         # 1. the mixture denominator of every earlier sample gains the current proposal

@@ -127,11 +127,12 @@ struct bild_amis {
             }
             if (pole) out = kInf;
         }
-        out += head[q][first[p]];
+        double disc = head[q][first[p]];
         const int32_t *pc = pcode.data() + (size_t)p * k;
         const double *pr = pair[q].data();
-        for (int i = 0; i < k; ++i) out += pr[pc[i]];
-        return out;
+        for (int i = 0; i < k; ++i) disc += pr[pc[i]];
+        // a trace of probability zero has density zero, also at a pole of the Dirichlet factor (+inf + -inf is not NaN here)
+        return disc == -kInf ? -kInf : out + disc;
     }
 };
 
@@ -512,7 +513,10 @@ int bild_amis_step(bild_amis *m, int64_t N, const double *ss, const int64_t *the
             for (int j = 0; j < k1; ++j) tot += mean[j] * (1 - mean[j]) / var[j];
             tot = tot / k1 - 1;
         }
-        for (int j = 0; j < k1; ++j) new_a[j] = tot * mean[j];
+        // weight on the boundary of the simplex (m_j = 1 up to rounding, or 0): negative / zero / non-finite
+        // concentration, with which the reference ends in "alpha <= 0"; treated like the degenerate case
+        if (!(std::isfinite(tot) && tot > 0)) tot = 1e10;
+        for (int j = 0; j < k1; ++j) new_a[j] = std::max(tot * mean[j], std::numeric_limits<double>::min());
     }
     // CFC: weighted slot marginals -> weights
     std::vector<double> new_logp((size_t)n * k1);
