@@ -81,7 +81,17 @@ class Dirichlet:
 
     def sample(self, a, N=1):
         """ (N, k+1) draws (bild/amis.py:66-81) """
-        return np.random.dirichlet(np.asarray(a, dtype=np.float64), size=N)   # the call scipy.stats.dirichlet.rvs makes
+        a = np.asarray(a, dtype=np.float64)
+        ss = np.random.dirichlet(a, size=N)   # the call scipy.stats.dirichlet.rvs makes
+        bad = ~np.all(np.isfinite(ss), axis=1)
+        if np.any(bad):
+            # All concentrations tiny (a bimodal posterior at the corners of the simplex drives their sum towards
+            # 0): every gamma variate of a draw underflows and NumPy returns 0/0.  The distribution is then, to all
+            # digits, a mixture of point masses at the corners with probabilities a_i / sum(a): draw from that.
+            # (Extra random numbers are consumed only here, where the reference goes on with NaN samples.)
+            corners = np.random.choice(len(a), size=int(np.sum(bad)), p=a / np.sum(a))
+            ss[bad] = np.eye(len(a))[corners]
+        return ss
 
     def logpdf(self, a, ss, log_ss=None):
         """
