@@ -98,10 +98,18 @@ def sample(traj, model,
             else:  # pragma: no cover
                 raise RuntimeError("Trying to sample outside of existing range; this is a bug")
 
+            progressed = state['fresh']
             k_next = next_k()
 
             if k_next == len(samplers):
-                running = True   # a new k takes precedence over the certainty criterion
+                # a new k takes precedence over the certainty criterion.  (When no sampler has taken a single step
+                # yet -- every k so far was enumerated exhaustively or has k >= T, i.e. a trajectory of a few frames
+                # -- the reference keeps opening samplers without looking at k_max, forever; here k_max ends it.)
+                running = k_next <= k_max
+            elif not progressed and samplers[k_next].exhausted:
+                # nothing was sampled in this round and the next candidate cannot sample either: the reference
+                # would spin on it; there is nothing left to learn
+                running = False
             else:
                 running = np.max(log['pk'][-1]) < certainty_in_k
                 if log['KLD'][-1] is not None:

@@ -242,3 +242,19 @@ def test_results_and_samplers_can_be_pickled_and_copied():
     assert np.array_equal(back.evidence, res.evidence) and back.best_k() == res.best_k()
     assert np.array_equal(back.best_profile()[:], res.best_profile()[:])
     assert np.allclose(back.log_marginal_posterior(), res.log_marginal_posterior(), rtol=0, atol=1e-12)
+
+
+@pytest.mark.timeout(120)
+def test_sample_terminates_on_tiny_trajectories():
+    """
+    Trajectories of a few frames: every sampler is exhaustive (or has k >= T), no AMIS step is ever taken -- the
+    reference's loop then opens samplers forever; here it ends at k_max and the results are usable.
+    """
+    model = bild_amd.FactorizedModel([stats.maxwell(scale=0.1), stats.maxwell(scale=1)])
+    for data in ([0.1], [0.1, 3.0], [0.1, np.nan, 3.0], [0.1, 0.05, 3.0, 2.0]):
+        traj = bild_amd.Trajectory(np.array(data))
+        np.random.seed(1)
+        res = bild_amd.sample(traj, model, k_max=6)
+        assert len(res.samplers) <= 7 + 1 and all(s.exhausted for s in res.samplers)
+        assert len(res.best_profile()) == len(data)
+        assert _normalised(res.log_marginal_posterior())
