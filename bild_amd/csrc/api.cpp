@@ -529,13 +529,18 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, st));
     }
-    int lrc = m.wide ? launch_logl_wide(m.NP, p, grid, (void *)st) : launch_logl(geom, mode, p, grid, lds, (void *)st);
+    // the dense recursion runs on the matrix pipe where the chain tiles into 4x4 blocks (BILD_DENSE_VALU=1: the
+    // LDS-fed vector formulation of kernels.hip instead)
+    const bool dense_mfma = !m.wide && mode == kDense && dense_mfma_supported(m.NP) && !getenv("BILD_DENSE_VALU");
+    int lrc = m.wide       ? launch_logl_wide(m.NP, p, grid, (void *)st)
+              : dense_mfma ? launch_logl_dense_mfma(m.NP, p, (void *)st)
+                           : launch_logl(geom, mode, p, grid, lds, (void *)st);
     if (lrc != 0) return fail(BILD_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
     if (timing) {
         HIP_TRY(hipEventRecord(e1, st));
         std::lock_guard<std::mutex> lk(g_time_mu);
         g_time_events.emplace_back(e0, e1);
-        g_time_name = m.wide ? "logl_wide_kernel" : kernel_name(geom, mode);
+        g_time_name = m.wide ? "logl_wide_kernel" : (dense_mfma ? "logl_dense_mfma_kernel" : kernel_name(geom, mode));
     }
     if (ts.dstar_max > 1) {
         lrc = launch_reduce_partials(target, d_out, n, ts.dstar_max, (void *)st);

@@ -85,6 +85,9 @@ int padded_rows(int n_rows);
 // task when fewer mean vectors are needed); env BILD_GEOM=<id> overrides.
 bool geometry_for(int NP, int mode, int64_t ntasks, int means, Geometry *g);
 const char *kernel_name(const Geometry &g, int mode);
+// dense recursion on the fp64 matrix pipe (dense_mfma.hip): NP a multiple of 4, <= 24
+bool dense_mfma_supported(int NP);
+int launch_logl_dense_mfma(int NP, const KParams &p, void *stream);
 // chains of more than kMaxNP modes (wide.hip): one task per workgroup, state in LDS
 size_t wide_lds_bytes(int NP);
 int launch_logl_wide(int NP, const KParams &p, int grid, void *stream);

@@ -28,10 +28,12 @@
 //   them.  Same code path as the modal basis change.
 // * Propagator / basis-change matrices are staged once per workgroup into LDS and read
 //   as group-wide broadcasts (ds_read_b128); one LDS operand pair feeds 2*CPL FMAs per row.
-// * fp64 throughout (v_fma_f64).  On gfx950 the f64 matrix pipe has the same peak as -- and, measured,
-//   shares its FMA throughput with -- the f64 vector pipe, and the modal predict is elementwise, so
-//   there is no GEMM to move there; the one use tried (the cross-lane sum S = s2 + w.(Cw) as two
-//   v_mfma_f64_4x4x4_4b, "block layout" below) gains 2-5 % and is kept as an opt-in geometry.
+// * fp64 throughout (v_fma_f64).  The modal predict is elementwise, so there is no GEMM to move to the matrix
+//   pipe here (the one use tried in this kernel -- the cross-lane sum S = s2 + w.(Cw) as two
+//   v_mfma_f64_4x4x4_4b, "block layout" below -- gains 2-5 % and is an opt-in geometry: the f64 matrix
+//   and vector instructions draw on the same FMA throughput).  The DENSE recursion, which IS two small GEMMs
+//   per frame, runs on the matrix pipe in dense_mfma.hip whenever the chain tiles into 4x4 blocks; the kDense
+//   code below serves the other chain lengths.
 // * sum_t log S_t is accumulated as a running product with exponent extraction
 //   (frexp) and one log per task, instead of one log per frame.
 #include <hip/hip_runtime.h>

@@ -5,6 +5,8 @@ oracle on seeded inputs.
 
 Tolerance: |delta logL| < 1e-8 absolute (BASELINE.json north_star), fp64.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -464,3 +466,53 @@ def test_model_survives_pickling_and_copying(built_lib):
         assert clone._handle is None
         assert np.array_equal(clone.logL_st_batch(ss, thetas, traj), want)
     assert np.array_equal(model.logL_st_batch(ss, thetas, traj), want)      # the original is untouched
+
+
+@pytest.mark.parametrize('case', ['N8', 'N24', 'N20_full', 'N16_3state_full', 'N12_force_full'])
+def test_dense_path_on_the_matrix_pipe(built_lib, case):
+    """
+    dense_mfma.hip (chains that tile into 4x4 blocks): four tasks per wavefront with different trajectories, lengths,
+    missing frames, states and switch times; against the oracle and against the vector formulation of the same path
+    """
+    import bild_amd
+    from bild_amd import _lib
+    from bild_amd.profiles import segments_from_st
+    from oracle import oracle
+    rng = np.random.default_rng(len(case))
+    N, S, reduce, d, err = {'N8': (8, 2, True, 3, 0.1), 'N24': (24, 2, True, 2, [0.1, 0.3]), 'N20_full': (20, 2, False, 3, 0.1),
+                            'N16_3state_full': (16, 3, False, 3, [0.1, 0.1, 0.2]), 'N12_force_full': (12, 2, False, 3, 0.2)}[case]
+    model = bild_amd.MultiStateRouse(N, 1, 3, d=d, looppositions=H.LOOPS[S] if S == 3 else (None, (0, -1)),
+                                     localization_error=err, path='dense')
+    if case == 'N12_force_full':
+        for mi, mod in enumerate(model.models):
+            mod.F[0, :] = [0.5, -0.25, 0.1 * (mi + 1)]
+            mod.F[-1, :] = [-0.5, 0.25, -0.1 * (mi + 1)]
+            mod.update_dynamics()
+    a = model.arrays()
+    model._handle = _lib.ModelHandle(a['B'], a['G'], a['Sig'], a['M0'], a['C0'], model.measurement, reduce=reduce)
+    assert model.handle().query(_lib.Q_NP) % 4 == 0
+    trajs, seg_start, seg_state, tid, want = [], [], [], [], []
+    K = 5
+    for j, T in enumerate([150, 37, 211, 64, 5]):
+        tr = model.trajectory_from_loopingprofile(H.random_profile(rng, T, S, max(T // 4, 2)), missing_frames=0.07 * j if T > 8 else None, rng=rng)
+        trajs.append(tr)
+        ss, thetas = H.candidate_profiles(rng, 21, K, S)
+        sa, sb = segments_from_st(ss, thetas, T)
+        seg_start.append(sa)
+        seg_state.append(sb)
+        tid += [j] * 21
+        want.append(oracle.logl_batch(a, model.measurement, model.localization_error, tr[:], H.expand(ss, thetas, T)))
+    perm = rng.permutation(len(tid))                       # neighbouring tasks of a wave differ in everything
+    seg_start, seg_state = np.concatenate(seg_start)[perm], np.concatenate(seg_state)[perm]
+    tid, want = np.asarray(tid)[perm], np.concatenate(want)[perm]
+    _lib.kernel_timing(True)
+    got = model.logL_segments(seg_start, seg_state, trajs, tid)
+    _lib.kernel_timing(False)
+    assert _lib.kernel_timing_read()[2] == 'logl_dense_mfma_kernel'
+    assert np.max(np.abs(got - want)) < TOL
+    os.environ['BILD_DENSE_VALU'] = '1'
+    try:
+        valu = model.logL_segments(seg_start, seg_state, trajs, tid)
+    finally:
+        del os.environ['BILD_DENSE_VALU']
+    assert np.max(np.abs(got - valu)) < 1e-9
