@@ -18,7 +18,7 @@
 //     C -= u u^T/S   A<-U[i] (row form read transposed: column 0 is u)  x  B<-U[j] * (-1/S)   accumulated into C
 //     M += u e^T/S   A<-U[i]  x  B<-E/S   with E the row-form tile of the innovation x - w^T M
 // so the state never leaves registers and no LDS is used at all.  Per frame and wavefront (4 tasks, NP = 20):
-// 337 matrix instructions and ~40 vector ones, against ~2600 vector FMAs per task in the LDS-fed formulation.
+// 297 matrix instructions and ~40 vector ones, against ~2600 vector FMAs per task in the LDS-fed formulation.
 // Tasks of a wave may be in different states (per-lane copies of the B / Sig tiles, reloaded at a switch), have
 // different lengths and missing frames (their update is scaled by 0; finished tasks keep propagating harmlessly).
 #include <hip/hip_runtime.h>
@@ -114,6 +114,7 @@ __global__ void __launch_bounds__(256, 1) logl_dense_mfma_kernel(const KParams p
             }
         }
 
+        const double eye = x == y ? 1.0 : 0.0; // the 4x4 identity as a tile
         double acc = 0.0; // sum of e^2 / S of this lane's dimension
         double P = 1.0;   // running product of S (mantissa), exponent in E
         int E = 0;
@@ -148,15 +149,22 @@ __global__ void __launch_bounds__(256, 1) logl_dense_mfma_kernel(const KParams p
                         for (int k = 0; k < NT; ++k) a = mma(Ct[k][i], Bt[k][j], a);
                         Y[i][j] = a;
                     }
+                // C' is symmetric: only the tiles on and above the diagonal are multiplied out, the others are their
+                // transposes -- one instruction each (the tile read as A, i.e. transposed, times the identity) instead
+                // of NT; it also keeps C exactly symmetric, which the A-operand trick above relies on
 #pragma unroll
                 for (int i = 0; i < NT; ++i)
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) {
+                    for (int j = i; j < NT; ++j) {
                         double a = St[i][j];
 #pragma unroll
                         for (int k = 0; k < NT; ++k) a = mma(Bt[k][i], Y[k][j], a);
                         Ct[i][j] = a;
                     }
+#pragma unroll
+                for (int i = 1; i < NT; ++i)
+#pragma unroll
+                    for (int j = 0; j < i; ++j) Ct[i][j] = mma(Ct[j][i], eye, 0.0);
                 double Mn[NT];
 #pragma unroll
                 for (int i = 0; i < NT; ++i) {
