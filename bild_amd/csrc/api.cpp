@@ -106,7 +106,9 @@ struct bild_model {
     std::string modal_why;
     Mat lam, sigd, Q, wq, R, C0q, M0q, Gq; // S*n, S*n, S*n*n, S*n, S*S*n*n, S*n*n, S*n*d, S*n*d
     // packed for the kernels
-    int NP = 0; // padded row count; the launch geometry is chosen per batch (geometry_for)
+    int NP = 0; // padded row count of the modal packing; the launch geometry is chosen per batch (geometry_for)
+    int NPm[2] = {0, 0}; // padded row count per path (kDense, kModal): the dense packing is rounded up to whole 4x4 tiles
+                         // where the matrix-pipe kernel applies (dense_mfma.hip)
     bool wide = false; // NP > kMaxNP: LDS-resident kernel (wide.hip), modal path only
     Mat blob_states[2], blob_tab[2];
     // device residency
@@ -384,10 +386,12 @@ int analyse(bild_model &m)
         m.NP = (n + 1) & ~1;
         m.wide = true;
     }
-    const int NP = m.NP;
-    const int SB = StateBlock::size(NP);
-    const int MS = table_stride(NP);
+    m.NPm[kModal] = m.NP;
+    m.NPm[kDense] = (!m.wide && dense_mfma_supported((n + 3) & ~3)) ? ((n + 3) & ~3) : m.NP;
     for (int mode = 0; mode < 2; ++mode) {
+        const int NP = m.NPm[mode];
+        const int SB = StateBlock::size(NP);
+        const int MS = table_stride(NP);
         Mat &sb = m.blob_states[mode];
         Mat &tb = m.blob_tab[mode];
         sb.assign((size_t)S * SB, 0.0);
@@ -482,8 +486,8 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
             return fail(BILD_ERR_UNSUPPORTED, "chains of more than %d effective modes (here %d) run on the modal path only%s%s", kMaxNP,
                         m.n, m.modal_ok ? "" : ", which is unavailable: ", m.modal_ok ? "" : m.modal_why.c_str());
     } else {
-        if (!geometry_for(m.NP, mode, n * ts.dstar_max, ts.means_max, &geom))
-            return fail(BILD_ERR_UNSUPPORTED, "no kernel for %d rows", m.NP);
+        if (!geometry_for(m.NPm[mode], mode, n * ts.dstar_max, ts.means_max, &geom))
+            return fail(BILD_ERR_UNSUPPORTED, "no kernel for %d rows", m.NPm[mode]);
         lds = lds_bytes(m, geom, mode);
         if (lds > 160 * 1024)
             return fail(BILD_ERR_UNSUPPORTED, "model tables need %zu bytes of LDS (> 160 KiB): too many states for chain length %d", lds, m.n);
@@ -531,9 +535,9 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
     }
     // the dense recursion runs on the matrix pipe where the chain tiles into 4x4 blocks (BILD_DENSE_VALU=1: the
     // LDS-fed vector formulation of kernels.hip instead)
-    const bool dense_mfma = !m.wide && mode == kDense && dense_mfma_supported(m.NP) && !getenv("BILD_DENSE_VALU");
+    const bool dense_mfma = !m.wide && mode == kDense && dense_mfma_supported(m.NPm[kDense]) && !getenv("BILD_DENSE_VALU");
     int lrc = m.wide       ? launch_logl_wide(m.NP, p, grid, (void *)st)
-              : dense_mfma ? launch_logl_dense_mfma(m.NP, p, (void *)st)
+              : dense_mfma ? launch_logl_dense_mfma(m.NPm[kDense], p, (void *)st)
                            : launch_logl(geom, mode, p, grid, lds, (void *)st);
     if (lrc != 0) return fail(BILD_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
     if (timing) {
