@@ -110,6 +110,7 @@ struct bild_model {
     int NPm[2] = {0, 0}; // padded row count per path (kDense, kModal): the dense packing is rounded up to whole 4x4 tiles
                          // where the matrix-pipe kernel applies (dense_mfma.hip)
     bool wide = false; // NP > kMaxNP: LDS-resident kernel (wide.hip), modal path only
+    bool symmetric = true; // B, Sig, C0 symmetric (what the reference's dsymv calls assume)
     Mat blob_states[2], blob_tab[2];
     // device residency
     mutable std::mutex mu;      // device residency and workspace growth
@@ -308,6 +309,7 @@ int analyse(bild_model &m)
 
     // ---- modal analysis ---------------------------------------------------------------
     m.modal_ok = symmetric;
+    m.symmetric = symmetric;
     m.modal_why = symmetric ? "" : "B, Sig or C0 is not symmetric";
     m.lam.assign((size_t)S * n, 0.0);
     m.sigd.assign((size_t)S * n, 0.0);
@@ -387,7 +389,8 @@ int analyse(bild_model &m)
         m.wide = true;
     }
     m.NPm[kModal] = m.NP;
-    m.NPm[kDense] = (!m.wide && dense_mfma_supported((n + 3) & ~3)) ? ((n + 3) & ~3) : m.NP;
+    // the matrix-pipe kernel reads tiles transposed and relies on B, Sig, C0 being symmetric
+    m.NPm[kDense] = (!m.wide && m.symmetric && dense_mfma_supported((n + 3) & ~3)) ? ((n + 3) & ~3) : m.NP;
     for (int mode = 0; mode < 2; ++mode) {
         const int NP = m.NPm[mode];
         const int SB = StateBlock::size(NP);
@@ -535,7 +538,7 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
     }
     // the dense recursion runs on the matrix pipe where the chain tiles into 4x4 blocks (BILD_DENSE_VALU=1: the
     // LDS-fed vector formulation of kernels.hip instead)
-    const bool dense_mfma = !m.wide && mode == kDense && dense_mfma_supported(m.NPm[kDense]) && !getenv("BILD_DENSE_VALU");
+    const bool dense_mfma = !m.wide && m.symmetric && mode == kDense && dense_mfma_supported(m.NPm[kDense]) && !getenv("BILD_DENSE_VALU");
     int lrc = m.wide       ? launch_logl_wide(m.NP, p, grid, (void *)st)
               : dense_mfma ? launch_logl_dense_mfma(m.NPm[kDense], p, (void *)st)
                            : launch_logl(geom, mode, p, grid, lds, (void *)st);
