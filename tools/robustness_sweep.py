@@ -4,7 +4,7 @@ Default-settings inference over a spread of synthetic trajectories (0-6 true swi
 and three states, 20 to 80 monomers, up to 20 % missing frames, weak to strong signal): does every run complete, and
 how good are the answers?
 
-    python tools/robustness_sweep.py [n_traj] [seed]
+    python tools/robustness_sweep.py [n_traj] [seed] [longest T]
 """
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,6 +13,7 @@ import numpy as np, helpers as H, bild_amd
 
 n_traj = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+T_hi = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
 rng = np.random.default_rng(seed)
 total_fail, total, t_all = 0, 0, 0.0
 GROUPS = (  # d, localization error, spring constant, monomers, loop positions (one per state)
@@ -26,7 +27,7 @@ for d, err, kspring, N, loops in GROUPS:
     S = len(loops)
     trajs, truths = [], []
     for j in range(n_traj // len(GROUPS)):
-        T = int(rng.integers(80, 1001))
+        T = int(rng.integers(80, T_hi + 1))
         nsw = int(rng.integers(0, 7))
         cuts = np.sort(rng.choice(np.arange(5, T - 5), size=nsw, replace=False)) if nsw else np.array([], int)
         truth = np.zeros(T, dtype=int)
