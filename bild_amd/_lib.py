@@ -74,6 +74,31 @@ _SIGNATURES = {
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """
+    A PyTorch-ROCm wheel ships its own HIP runtime (same soname as the system one).  Two runtimes in one process do
+    not coexist: if this library brings in the system runtime first, a later ``torch.cuda`` finds "No HIP GPUs".
+    So when PyTorch is installed but not loaded yet, its runtime is loaded first and the library binds to it -- the
+    same arrangement as when torch is imported before bild_amd.  ``BILD_AMD_HIP_RUNTIME=system`` skips this.
+    """
+    import importlib.util
+    import sys
+    if 'torch' in sys.modules or os.environ.get('BILD_AMD_HIP_RUNTIME') == 'system':
+        return
+    try:
+        spec = importlib.util.find_spec('torch')
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    path = os.path.join(os.path.dirname(spec.origin), 'lib', 'libamdhip64.so')
+    if os.path.exists(path):
+        try:
+            ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """ load libbild_amd.so (raises if it has not been built) """
     global _lib
@@ -81,6 +106,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                               f"or `make -C bild_amd/csrc` (there is no CPU fallback)")
+        _share_hip_runtime_with_torch()
         handle = ctypes.CDLL(LIB_PATH)
         for name, (restype, argtypes) in _SIGNATURES.items():
             fn = getattr(handle, name)

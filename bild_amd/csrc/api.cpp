@@ -25,6 +25,7 @@ using la::Mat;
 // ------------------------------------------------------------------------------------
 namespace {
 
+
 thread_local std::string g_err;
 
 int fail(int code, const char *fmt, ...)
@@ -109,7 +110,8 @@ struct bild_model {
     int NP = 0; // padded row count of the modal packing; the launch geometry is chosen per batch (geometry_for)
     int NPm[2] = {0, 0}; // padded row count per path (kDense, kModal): the dense packing is rounded up to whole 4x4 tiles
                          // where the matrix-pipe kernel applies (dense_mfma.hip)
-    bool wide = false; // NP > kMaxNP: LDS-resident kernel (wide.hip), modal path only
+    bool wide = false; // NP > kMidMaxNP: LDS-resident kernel (wide.hip), modal path only
+    bool mid = false;  // kMaxNP < NP <= kMidMaxNP: tile-register kernel (modal_mfma.hip), modal path only
     bool symmetric = true; // B, Sig, C0 symmetric (what the reference's dsymv calls assume)
     Mat blob_states[2], blob_tab[2];
     // device residency
@@ -385,12 +387,17 @@ int analyse(bild_model &m)
     if (!m.NP) {
         if (n > kWideMaxNP)
             return fail(BILD_ERR_UNSUPPORTED, "chain of %d effective modes exceeds the kernels (max %d)", n, kWideMaxNP);
-        m.NP = (n + 1) & ~1;
-        m.wide = true;
+        if (n <= kMidMaxNP) {
+            m.NP = (n + 3) & ~3;
+            m.mid = true;
+        } else {
+            m.NP = (n + 1) & ~1;
+            m.wide = true;
+        }
     }
     m.NPm[kModal] = m.NP;
     // the matrix-pipe kernel reads tiles transposed and relies on B, Sig, C0 being symmetric
-    m.NPm[kDense] = (!m.wide && m.symmetric && dense_mfma_supported((n + 3) & ~3)) ? ((n + 3) & ~3) : m.NP;
+    m.NPm[kDense] = (!m.wide && !m.mid && m.symmetric && dense_mfma_supported((n + 3) & ~3)) ? ((n + 3) & ~3) : m.NP;
     for (int mode = 0; mode < 2; ++mode) {
         const int NP = m.NPm[mode];
         const int SB = StateBlock::size(NP);
@@ -484,11 +491,13 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
     if (rc) return rc;
     Geometry geom{};
     size_t lds = 0;
-    if (m.wide) {
+    // 33-40 modes: the modal recursion on tile registers (modal_mfma.hip)
+    const bool modal_mfma = m.mid && mode == kModal && modal_mfma_supported(m.NPm[kModal]);
+    if (m.wide || m.mid) {
         if (mode != kModal)
             return fail(BILD_ERR_UNSUPPORTED, "chains of more than %d effective modes (here %d) run on the modal path only%s%s", kMaxNP,
                         m.n, m.modal_ok ? "" : ", which is unavailable: ", m.modal_ok ? "" : m.modal_why.c_str());
-    } else {
+    } else if (!modal_mfma) {
         if (!geometry_for(m.NPm[mode], mode, n * ts.dstar_max, ts.means_max, &geom))
             return fail(BILD_ERR_UNSUPPORTED, "no kernel for %d rows", m.NPm[mode]);
         lds = lds_bytes(m, geom, mode);
@@ -521,7 +530,9 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
     }
     p.out = target;
 
-    const int64_t tasks_per_block = m.wide ? 1 : (int64_t)geom.W * geom.tasks_per_wave();
+    // (the matrix-pipe kernels size their own grid: 16 tasks per workgroup)
+    const bool tiled = modal_mfma || (!m.wide && m.symmetric && mode == kDense && dense_mfma_supported(m.NPm[kDense]) && !getenv("BILD_DENSE_VALU"));
+    const int64_t tasks_per_block = m.wide ? 1 : tiled ? 16 : (int64_t)geom.W * geom.tasks_per_wave();
     int64_t blocks = (p.ntasks + tasks_per_block - 1) / tasks_per_block;
     const int grid = (int)std::min<int64_t>(std::max<int64_t>(blocks, 1), 256 * 16);
 
@@ -540,6 +551,7 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
     // LDS-fed vector formulation of kernels.hip instead)
     const bool dense_mfma = !m.wide && m.symmetric && mode == kDense && dense_mfma_supported(m.NPm[kDense]) && !getenv("BILD_DENSE_VALU");
     int lrc = m.wide       ? launch_logl_wide(m.NP, p, grid, (void *)st)
+              : modal_mfma ? launch_logl_modal_mfma(m.NPm[kModal], p, (void *)st)
               : dense_mfma ? launch_logl_dense_mfma(m.NPm[kDense], p, (void *)st)
                            : launch_logl(geom, mode, p, grid, lds, (void *)st);
     if (lrc != 0) return fail(BILD_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
@@ -547,7 +559,7 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
         HIP_TRY(hipEventRecord(e1, st));
         std::lock_guard<std::mutex> lk(g_time_mu);
         g_time_events.emplace_back(e0, e1);
-        g_time_name = m.wide ? "logl_wide_kernel" : (dense_mfma ? "logl_dense_mfma_kernel" : kernel_name(geom, mode));
+        g_time_name = m.wide ? "logl_wide_kernel" : modal_mfma ? "logl_modal_mfma_kernel" : dense_mfma ? "logl_dense_mfma_kernel" : kernel_name(geom, mode);
     }
     if (ts.dstar_max > 1) {
         lrc = launch_reduce_partials(target, d_out, n, ts.dstar_max, (void *)st);

@@ -88,7 +88,11 @@ const char *kernel_name(const Geometry &g, int mode);
 // dense recursion on the fp64 matrix pipe (dense_mfma.hip): NP a multiple of 4, <= 24
 bool dense_mfma_supported(int NP);
 int launch_logl_dense_mfma(int NP, const KParams &p, void *stream);
-// chains of more than kMaxNP modes (wide.hip): one task per workgroup, state in LDS
+// modal recursion on tile registers (modal_mfma.hip): NP = 36, 40
+constexpr int kMidMaxNP = 40;
+bool modal_mfma_supported(int NP);
+int launch_logl_modal_mfma(int NP, const KParams &p, void *stream);
+// chains of more than kMidMaxNP modes (wide.hip): one task per workgroup, state in LDS
 size_t wide_lds_bytes(int NP);
 int launch_logl_wide(int NP, const KParams &p, int grid, void *stream);
 

@@ -516,3 +516,71 @@ def test_dense_path_on_the_matrix_pipe(built_lib, case):
     finally:
         del os.environ['BILD_DENSE_VALU']
     assert np.max(np.abs(got - valu)) < 1e-9
+
+
+@pytest.mark.parametrize('case', ['N72', 'N36_full_3state', 'N80_force'])
+def test_modal_recursion_on_tile_registers(built_lib, case):
+    """
+    modal_mfma.hip (33-40 modes): four tasks per wavefront with different trajectories, lengths, missing frames and
+    switch times (a switch of one task makes the whole wave run the basis change, the others with the identity)
+    """
+    import bild_amd
+    from bild_amd import _lib
+    from bild_amd.profiles import segments_from_st
+    from oracle import oracle
+    rng = np.random.default_rng(len(case) + 3)
+    N, S, reduce, d, err = {'N72': (72, 2, True, 3, 0.1), 'N36_full_3state': (36, 3, False, 2, [0.1, 0.25]),
+                            'N80_force': (80, 2, True, 3, [0.1, 0.1, 0.2])}[case]
+    model = bild_amd.MultiStateRouse(N, 1, 3, d=d, looppositions=H.LOOPS[S] if S == 3 else (None, (0, -1)), localization_error=err)
+    if case == 'N80_force':
+        for mi, mod in enumerate(model.models):
+            mod.F[0, :] = [0.5, -0.25, 0.1 * (mi + 1)]
+            mod.F[-1, :] = [-0.5, 0.25, -0.1 * (mi + 1)]
+            mod.update_dynamics()
+    a = model.arrays()
+    model._handle = _lib.ModelHandle(a['B'], a['G'], a['Sig'], a['M0'], a['C0'], model.measurement, reduce=reduce)
+    assert 32 < model.handle().query(_lib.Q_NEFF) <= 40
+    trajs, seg_start, seg_state, tid, want = [], [], [], [], []
+    K = 5
+    for j, T in enumerate([90, 37, 121, 64, 5]):
+        tr = model.trajectory_from_loopingprofile(H.random_profile(rng, T, S, max(T // 4, 2)), missing_frames=0.07 * j if T > 8 else None, rng=rng)
+        trajs.append(tr)
+        ss, thetas = H.candidate_profiles(rng, 9, K, S)
+        sa, sb = segments_from_st(ss, thetas, T)
+        seg_start.append(sa)
+        seg_state.append(sb)
+        tid += [j] * 9
+        want.append(oracle.logl_batch(a, model.measurement, model.localization_error, tr[:], H.expand(ss, thetas, T)))
+    perm = rng.permutation(len(tid))
+    seg_start, seg_state = np.concatenate(seg_start)[perm], np.concatenate(seg_state)[perm]
+    tid, want = np.asarray(tid)[perm], np.concatenate(want)[perm]
+    _lib.kernel_timing(True)
+    got = model.logL_segments(seg_start, seg_state, trajs, tid)
+    _lib.kernel_timing(False)
+    assert _lib.kernel_timing_read()[2] == 'logl_modal_mfma_kernel'
+    assert np.max(np.abs(got - want)) < TOL
+
+
+def test_torch_after_the_library(built_lib):
+    """
+    A PyTorch-ROCm wheel brings its own HIP runtime; the library binds to it when torch is installed, so that
+    ``torch.cuda`` still works when it is first used AFTER the library (it found "No HIP GPUs" otherwise).
+    """
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')\n"
+              "import numpy as np, helpers as H, bild_amd\n"
+              "assert 'torch' not in sys.modules\n"
+              "m = bild_amd.MultiStateRouse(20, 1, 5, d=3, localization_error=0.1)\n"
+              "rng = np.random.default_rng(0)\n"
+              "tr = m.trajectory_from_loopingprofile(H.random_profile(rng, 50, 2, 20), rng=rng)\n"
+              "ss, th = H.candidate_profiles(rng, 4, 2, 2)\n"
+              "a = m.logL_st_batch(ss, th, tr)\n"
+              "import torch\n"
+              "assert torch.cuda.is_available()\n"
+              "assert torch.zeros(3, device='cuda').sum().item() == 0\n"
+              "assert np.array_equal(m.logL_st_batch(ss, th, tr), a)\n"
+              "print('ORDER_OK')\n") % (root, root)
+    r = subprocess.run([sys.executable, '-c', script], capture_output=True, text=True, timeout=300)
+    assert 'ORDER_OK' in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
