@@ -489,15 +489,25 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
     int mode;
     int rc = pick_mode(m, flags, &mode);
     if (rc) return rc;
-    Geometry geom{};
-    size_t lds = 0;
-    // 33-40 modes: the modal recursion on tile registers (modal_mfma.hip)
-    const bool modal_mfma = m.mid && mode == kModal && modal_mfma_supported(m.NPm[kModal]);
+    // which kernel family serves this model and path:
+    //   kWide       41-128 modes, LDS-resident state (wide.hip)                      modal path only
+    //   kModalTiles 33-40 modes, modal recursion on tile registers (modal_mfma.hip)  modal path only
+    //   kDenseTiles dense recursion on the matrix pipe (dense_mfma.hip): symmetric models of up to 24 modes
+    //               (BILD_DENSE_VALU=1: the LDS-fed vector formulation instead)
+    //   kVector     the register-resident vector kernels of kernels.hip, geometry chosen per batch
+    enum Family { kVector, kDenseTiles, kModalTiles, kWide };
+    Family fam = kVector;
     if (m.wide || m.mid) {
         if (mode != kModal)
             return fail(BILD_ERR_UNSUPPORTED, "chains of more than %d effective modes (here %d) run on the modal path only%s%s", kMaxNP,
                         m.n, m.modal_ok ? "" : ", which is unavailable: ", m.modal_ok ? "" : m.modal_why.c_str());
-    } else if (!modal_mfma) {
+        fam = m.wide ? kWide : kModalTiles;
+    } else if (mode == kDense && m.symmetric && dense_mfma_supported(m.NPm[kDense]) && !getenv("BILD_DENSE_VALU")) {
+        fam = kDenseTiles;
+    }
+    Geometry geom{};
+    size_t lds = 0;
+    if (fam == kVector) {
         if (!geometry_for(m.NPm[mode], mode, n * ts.dstar_max, ts.means_max, &geom))
             return fail(BILD_ERR_UNSUPPORTED, "no kernel for %d rows", m.NPm[mode]);
         lds = lds_bytes(m, geom, mode);
@@ -530,9 +540,8 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
     }
     p.out = target;
 
-    // (the matrix-pipe kernels size their own grid: 16 tasks per workgroup)
-    const bool tiled = modal_mfma || (!m.wide && m.symmetric && mode == kDense && dense_mfma_supported(m.NPm[kDense]) && !getenv("BILD_DENSE_VALU"));
-    const int64_t tasks_per_block = m.wide ? 1 : tiled ? 16 : (int64_t)geom.W * geom.tasks_per_wave();
+    // tasks per workgroup (the tile kernels size their own grid: 4 waves x 4 tasks)
+    const int64_t tasks_per_block = fam == kWide ? 1 : fam != kVector ? 16 : (int64_t)geom.W * geom.tasks_per_wave();
     int64_t blocks = (p.ntasks + tasks_per_block - 1) / tasks_per_block;
     const int grid = (int)std::min<int64_t>(std::max<int64_t>(blocks, 1), 256 * 16);
 
@@ -547,19 +556,16 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, st));
     }
-    // the dense recursion runs on the matrix pipe where the chain tiles into 4x4 blocks (BILD_DENSE_VALU=1: the
-    // LDS-fed vector formulation of kernels.hip instead)
-    const bool dense_mfma = !m.wide && m.symmetric && mode == kDense && dense_mfma_supported(m.NPm[kDense]) && !getenv("BILD_DENSE_VALU");
-    int lrc = m.wide       ? launch_logl_wide(m.NP, p, grid, (void *)st)
-              : modal_mfma ? launch_logl_modal_mfma(m.NPm[kModal], p, (void *)st)
-              : dense_mfma ? launch_logl_dense_mfma(m.NPm[kDense], p, (void *)st)
-                           : launch_logl(geom, mode, p, grid, lds, (void *)st);
+    int lrc = fam == kWide         ? launch_logl_wide(m.NP, p, grid, (void *)st)
+              : fam == kModalTiles ? launch_logl_modal_mfma(m.NPm[kModal], p, (void *)st)
+              : fam == kDenseTiles ? launch_logl_dense_mfma(m.NPm[kDense], p, (void *)st)
+                                   : launch_logl(geom, mode, p, grid, lds, (void *)st);
     if (lrc != 0) return fail(BILD_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
     if (timing) {
         HIP_TRY(hipEventRecord(e1, st));
         std::lock_guard<std::mutex> lk(g_time_mu);
         g_time_events.emplace_back(e0, e1);
-        g_time_name = m.wide ? "logl_wide_kernel" : modal_mfma ? "logl_modal_mfma_kernel" : dense_mfma ? "logl_dense_mfma_kernel" : kernel_name(geom, mode);
+        g_time_name = fam == kWide ? "logl_wide_kernel" : fam == kModalTiles ? "logl_modal_mfma_kernel" : fam == kDenseTiles ? "logl_dense_mfma_kernel" : kernel_name(geom, mode);
     }
     if (ts.dstar_max > 1) {
         lrc = launch_reduce_partials(target, d_out, n, ts.dstar_max, (void *)st);
