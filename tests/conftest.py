@@ -14,10 +14,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
-@pytest.fixture(scope='session')
-def built_lib():
-    """ make sure libbild_amd.so exists (cross-compiles without a GPU) """
+@pytest.fixture(scope='session', autouse=True)
+def _build_once():
+    """
+    libbild_amd.so (cross-compiles without a GPU) and the oracle exist before any test runs: the samplers use the
+    library's host-side bookkeeping even in tests that never touch a GPU.  A no-op when everything is up to date.
+    """
     import __graft_entry__ as entry
     entry.build()
+
+
+@pytest.fixture(scope='session')
+def built_lib(_build_once):
+    """ the loaded library handle """
     from bild_amd import _lib
     return _lib.lib()
