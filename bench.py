@@ -2,14 +2,28 @@
 """
 Headline benchmark: logL evaluations / second of one AMIS batch on MI355X.
 
-Workload (BASELINE.json configs[1]): a batch of 10 000 candidate looping profiles x 1
-trajectory, T = 1000 frames, 2-state Rouse model, N = 20 monomers, d = 3, one localization
-error (d* = 1), k = 4 switches per candidate, fp64.  One "step" = one pass of the hot path
-over one such batch: everything `FixedkSampler.logL(ss, thetas)` does for one AMIS iteration
-(reference bild/amis.py:717-739), with the run-length encoded profiles and the trajectory
-already resident in HBM.  With N > 1 GPUs every rank evaluates its own 10k batch (weak
-scaling, one process per GPU) and the per-step result is exchanged with ONE all-gather of
-the log-likelihoods (RCCL), as an AMIS step needs them to form the importance weights.
+Workload (BASELINE.json configs[1]): a batch of 10 000 candidate looping profiles x 1 trajectory, T = 1000 frames,
+2-state Rouse model, N = 20 monomers, d = 3, one localization error (d* = 1), k = 4 switches per candidate, fp64.
+One "step" = one pass of the hot path over one such batch: everything `FixedkSampler.logL(ss, thetas)` does for one
+AMIS iteration (reference bild/amis.py:717-739).
+
+What the JSON line reports
+  value / ms_per_step   the batch with candidates and trajectory resident in HBM (`bild_logl_segments_device`,
+                        nothing crosses PCIe inside the timed region) -- the bench contract's definition;
+  api_seam              the SAME batch through the seam the path is defined by: `FixedkSampler.logL(ss, thetas)` with
+                        host arrays in and a host array out per step (native (s, theta) -> segment conversion, one
+                        packed H2D copy out of pinned memory, the launch, one D2H copy, one synchronisation);
+  roofline              the dominant kernel against the fp64 vector peak: `achieved` / `frac` count the operations the
+                        kernel really executes (frames skipped through shared prefixes are not counted);
+                        `canonical_equiv_frac` prices the same time against the reference's dense operation count
+                        (a speed-up figure, may exceed 1, never a utilisation);
+  cpu_baseline          the reference's own Cython kernel on one host core (and on all cores, secondary).
+
+Multi-GPU: one process per GPU.  `--scaling weak` (default, what the driver runs): every rank evaluates its own 10k
+batch and joins ONE all-gather of the log-likelihoods per step (RCCL), as an AMIS step needs them to form the
+importance weights.  `--scaling strong`: a FIXED workload is partitioned over the ranks -- `--strong-config 1`:
+configs[1] (10k x 1 trajectory, contiguous sample shards), `--strong-config 2`: configs[2] (256 trajectories x 1000
+samples, whole trajectories per rank, `dist.shard_by_trajectory`) -- again one all-gather per step.
 
     python bench.py --gpus 1 --steps 50 --warmup 5
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -30,25 +44,28 @@ FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector (= fp64 matrix) peak, AMD spec (S
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def build_workload(rank, n_samples, T, k, S=2, N=20, d=3, err=0.1):
+def build_workload(seed, n_samples, T, k, S=2, N=20, d=3, err=0.1, n_traj=1):
+    """ model, n_traj trajectories, and n_samples candidates per trajectory """
     import helpers as H
     import bild_amd
-    rng_t = np.random.default_rng(1000 + rank)
-    rng_c = np.random.default_rng(2000 + rank)
+    rng_t = np.random.default_rng(1000 + seed)
+    rng_c = np.random.default_rng(2000 + seed)
     model = bild_amd.MultiStateRouse(N, 1., 5., d=d, looppositions=H.LOOPS[S], localization_error=err)
-    truth = H.random_profile(rng_t, T, S, T // 5)
-    traj = model.trajectory_from_loopingprofile(truth, rng=rng_t)
-    ss, thetas = H.candidate_profiles(rng_c, n_samples, k, S)
-    return model, traj, ss, thetas
+    trajs = []
+    for _ in range(n_traj):
+        truth = H.random_profile(rng_t, T, S, T // 5)
+        trajs.append(model.trajectory_from_loopingprofile(truth, rng=rng_t))
+    ss, thetas = H.candidate_profiles(rng_c, n_samples * n_traj, k, S)
+    return model, trajs, ss, thetas
 
 
-def _cpu_baseline_loop(model, traj, ss, thetas, T, budget_s):
+def _cpu_baseline_loop(model, traj, ss, thetas, T, budget_s, first):
     """ the timed loop itself; runs in a child process (see cpu_baseline) """
     import helpers as H
     from oracle import oracle
     ref = oracle.load_reference_cython()
     kind = 'reference'
-    states = H.expand(ss[:8192], thetas[:8192], T)
+    states = H.expand(ss[first:first + 8192], thetas[first:first + 8192], T)
 
     class M:
         pass
@@ -69,35 +86,45 @@ def _cpu_baseline_loop(model, traj, ss, thetas, T, budget_s):
 
 
 def _cpu_baseline_child(argv):
-    """ `bench.py --cpu-baseline-child rank n T k S budget out.npz`: CPU only, never touches the GPU """
-    rank, n, T, k, S = (int(v) for v in argv[:5])
-    model, traj, ss, thetas = build_workload(rank, n, T, k, S=S)
-    kind, dt, out = _cpu_baseline_loop(model, traj, ss, thetas, T, float(argv[5]))
+    """ `bench.py --cpu-baseline-child seed n T k S budget out.npz first`: CPU only, never touches the GPU """
+    seed, n, T, k, S = (int(v) for v in argv[:5])
+    model, trajs, ss, thetas = build_workload(seed, n, T, k, S=S)
+    kind, dt, out = _cpu_baseline_loop(model, trajs[0], ss, thetas, T, float(argv[5]), int(argv[7]))
     np.savez(argv[6], kind=kind, dt=dt, out=out)
 
 
-def cpu_baseline(rank, n, T, k, S, budget_s=15.0):
+def cpu_baseline(seed, n, T, k, S, budget_s=15.0, procs=1):
     """
-    The reference's own Cython kernel (compiled unmodified into oracle/_ref) on ONE host core,
-    driven exactly like FixedkSampler.logL drives it (a Python loop, amis.py:735-739), on a
-    bounded sample of the same batch.  It runs in a fresh child process with the BLAS pools pinned to
-    one thread from the start: inside this process (torch loaded, pools limited after the fact) the
-    same loop is 20-35 % slower, which would flatter the GPU.
+    The reference's own Cython kernel (compiled unmodified into oracle/_ref) on host cores, driven exactly like
+    FixedkSampler.logL drives it (a Python loop, amis.py:735-739), on a bounded sample of the same batch.  Every
+    process is a fresh child with the BLAS pools pinned to one thread from the start: inside this process (torch
+    loaded, pools limited after the fact) the same loop is 20-35 % slower, which would flatter the GPU.
+    `procs` > 1: that many children at once over disjoint parts of the batch (one per core).
     """
     import subprocess
     import tempfile
     env = dict(os.environ, OPENBLAS_NUM_THREADS='1', OMP_NUM_THREADS='1', MKL_NUM_THREADS='1')
     with tempfile.TemporaryDirectory() as tmp:
-        path = os.path.join(tmp, 'cpu_baseline.npz')
-        subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-child',
-                        str(rank), str(n), str(T), str(k), str(S), str(budget_s), path],
-                       env=env, check=True, timeout=budget_s + 600)
-        with np.load(path) as z:
-            kind, dt, out = str(z['kind']), float(z['dt']), np.array(z['out'])
-    return dict(value=len(out) / dt, unit='evals/s', cores=1, kind=kind,
-                sample=f"first {len(out)} profiles of the rank-0 batch, T={T}, {dt:.1f} s of "
-                       f"{'reference Cython MSRouse_logL (oracle/_ref)' if kind == 'reference' else 'oracle C port'}"
-                       f" in a Python loop (amis.py:735-739), own process, BLAS pinned to 1 thread"), out
+        children = []
+        for c in range(procs):
+            path = os.path.join(tmp, f'cpu_baseline_{c}.npz')
+            first = (c * (n // procs)) if procs > 1 else 0
+            children.append((path, subprocess.Popen(
+                [sys.executable, os.path.abspath(__file__), '--cpu-baseline-child', str(seed), str(n), str(T), str(k),
+                 str(S), str(budget_s), path, str(first)], env=env)))
+        total, dts, outs, kind = 0, [], [], 'port'
+        for path, child in children:
+            if child.wait(timeout=budget_s + 600) != 0:
+                raise RuntimeError("cpu baseline child failed")
+            with np.load(path) as z:
+                kind = str(z['kind'])
+                dts.append(float(z['dt']))
+                outs.append(np.array(z['out']))
+                total += len(z['out'])
+    what = 'reference Cython MSRouse_logL (oracle/_ref)' if kind == 'reference' else 'oracle C port'
+    return dict(value=total / max(dts), unit='evals/s', cores=procs, kind=kind,
+                sample=f"{total} profiles of the rank-0 batch, T={T}, {max(dts):.1f} s of {what} in a Python loop "
+                       f"(amis.py:735-739), {procs} process(es), BLAS pinned to 1 thread each"), outs[0]
 
 
 def main():
@@ -105,19 +132,22 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--samples', type=int, default=10000, help='candidate profiles per GPU per step')
+    ap.add_argument('--samples', type=int, default=10000, help='candidate profiles per GPU per step (weak scaling)')
     ap.add_argument('--T', type=int, default=1000)
     ap.add_argument('--k', type=int, default=4)
     ap.add_argument('--states', type=int, default=2)
     ap.add_argument('--path', default='auto', choices=['auto', 'modal', 'dense'])
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
+    ap.add_argument('--strong-config', type=int, default=2, choices=[1, 2],
+                    help='strong scaling: 1 = configs[1] (10k x 1 trajectory) split over the ranks, '
+                         '2 = configs[2] (256 trajectories x 1000 samples) sharded by trajectory')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-allcores', action='store_true', help='also time the reference kernel on every host core')
     ap.add_argument('--no-reduce', action='store_true', help='keep all N modes (skip the invariant-subspace reduction)')
-    ap.add_argument('--no-dense', action='store_true', help='skip the secondary dense-path measurement')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the dense / canonical-path side measurements')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help="collective backend; 'gloo' (log-likelihoods staged through host memory) rehearses the "
                          "multi-rank path on a box with fewer GPUs than ranks")
-    ap.add_argument('--host-buffers', action='store_true',
-                    help='also time the host-buffer entry point (H2D of the profiles + D2H of the results per step)')
     args = ap.parse_args()
 
     import torch
@@ -147,45 +177,81 @@ def main():
     if world > 1:
         dist.barrier()
 
+    import bild_amd
     from bild_amd import _lib
     from bild_amd.profiles import segments_from_st
     from bild_amd import dist as bdist
 
-    n, T, k = args.samples, args.T, args.k
-    model, traj, ss, thetas = build_workload(rank, n, T, k, S=args.states)
+    T, k = args.T, args.k
+    dev = torch.device('cuda', dev_index)
+
+    # ---- the workload of this rank ------------------------------------------------------------------------
+    if args.scaling == 'weak':
+        n = args.samples
+        model, trajs, ss, thetas = build_workload(rank, n, T, k, S=args.states)
+        traj_id = None
+        n_global = n * world
+        sizes = [n] * world
+        workload = (f'configs[1]: {n} profile samples x 1 trajectory per GPU, T={T}, {args.states}-state Rouse N=20 d=3 '
+                    f'd*=1, k={k} switches, fp64')
+    elif args.strong_config == 1:
+        n_global = args.samples
+        model, trajs, ss, thetas = build_workload(0, n_global, T, k, S=args.states)
+        lo, hi = bdist.shard_bounds(n_global, world, rank)
+        ss, thetas, traj_id = ss[lo:hi], thetas[lo:hi], None
+        n = hi - lo
+        sizes = [b - a for a, b in (bdist.shard_bounds(n_global, world, r) for r in range(world))]
+        workload = (f'configs[1] strong: {n_global} profile samples x 1 trajectory split over {world} GPU(s), T={T}, '
+                    f'{args.states}-state, k={k}, fp64')
+    else:
+        n_traj_total, per = 256, 1000
+        model, trajs_all, ss_all, thetas_all = build_workload(0, per, T, k, S=args.states, n_traj=n_traj_total)
+        owners = bdist.shard_by_trajectory([T] * n_traj_total, [per] * n_traj_total, world)
+        mine = owners[rank]
+        trajs = [trajs_all[j] for j in mine]
+        rows = np.concatenate([np.arange(j * per, (j + 1) * per) for j in mine])
+        ss, thetas = ss_all[rows], thetas_all[rows]
+        traj_id = np.repeat(np.arange(len(mine)), per).astype(np.int32)
+        n = len(rows)
+        n_global = n_traj_total * per
+        sizes = [len(o) * per for o in owners]
+        workload = (f'configs[2] strong: {n_traj_total} trajectories x {per} samples sharded by trajectory over {world} '
+                    f'GPU(s) ({len(mine)} trajectories on this rank), T={T}, {args.states}-state, k={k}, fp64')
+
     model.path = args.path
     if args.no_reduce:
         a_ = model.arrays()
         model._handle = _lib.ModelHandle(a_['B'], a_['G'], a_['Sig'], a_['M0'], a_['C0'], model.measurement, reduce=False)
     h = model.handle()
-    ts = model.trajset(traj)                          # trajectory resident in HBM
+    ts = model.trajset(trajs if traj_id is not None else trajs[0])      # trajectories resident in HBM
     seg_start, seg_state = segments_from_st(ss, thetas, T)
-    dev = torch.device('cuda', dev_index)
-    d_start = torch.from_numpy(seg_start).to(dev)     # candidates resident in HBM
+    d_start = torch.from_numpy(seg_start).to(dev)                        # candidates resident in HBM
     d_state = torch.from_numpy(seg_state).to(dev)
-    d_out = torch.empty(n, dtype=torch.float64, device=dev)
-    d_all = torch.empty(n * world, dtype=torch.float64, device=dev)
+    d_tid = torch.from_numpy(traj_id).to(dev) if traj_id is not None else None
+    pad = max(sizes)
+    d_out = torch.zeros(pad, dtype=torch.float64, device=dev)
+    d_all = torch.empty(pad * world, dtype=torch.float64, device=dev)
 
     def step(path):
         stream = torch.cuda.current_stream().cuda_stream
-        _lib.logl_segments_device(h, ts, n, k + 1, d_start.data_ptr(), d_state.data_ptr(), 0, d_out.data_ptr(),
-                                  stream=stream, path=path)
+        _lib.logl_segments_device(h, ts, n, k + 1, d_start.data_ptr(), d_state.data_ptr(),
+                                  d_tid.data_ptr() if d_tid is not None else 0, d_out.data_ptr(), stream=stream, path=path)
         if world > 1:                                 # the one collective of an AMIS step
             if args.backend == 'nccl':
                 bdist.all_gather_logl(d_out, d_all)
             else:
                 d_all.copy_(bdist.all_gather_logl(d_out.cpu()))
 
-    def timed(path, steps, warmup):
+    def timed(fn, steps, warmup):
         for _ in range(warmup):
-            step(path)
+            fn()
         _lib.kernel_timing(True)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
-            step(path)
+            fn()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -198,109 +264,116 @@ def main():
             dt = float(t.item())
         return dt, kms / max(launches, 1), kname
 
-    dt, kernel_ms, kname = timed(args.path, args.steps, args.warmup)
-    value = world * n * args.steps / dt
+    dt, kernel_ms, kname = timed(lambda: step(args.path), args.steps, args.warmup)
+    value = n_global * args.steps / dt
 
-    # HBM bytes per launch measured with rocprofv3 PMC passes (profiles/*_hbm_traffic.json), quoted only
-    # when the committed measurement is for this very workload
+    # ---- roofline of the dominant kernel: executed operations against the fp64 vector peak --------------------
     traffic = None
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')) as f:
+        with open(os.path.join(ROOT, 'profiles', 'r02_hbm_traffic.json')) as f:
             tj = json.load(f)
         if tj['workload'] == {'samples': n, 'T': T, 'k': k, 'path': args.path} and args.states == 2:
-            traffic = tj['traffic_bytes_raw']
+            traffic = tj['traffic_bytes_corrected']
     except Exception:
         pass
-    can, exe = _lib.flop_count(h, ts, n, path=args.path)
+    can, exe = _lib.flop_count(h, ts, n, traj_id=traj_id, path=args.path)
+    frames_frac = _lib.frames_executed_fraction(h, ts, seg_start, traj_id, path=args.path) if hasattr(_lib, 'frames_executed_fraction') else 1.0
+    exe *= frames_frac
     ksec = kernel_ms * 1e-3
+    is_mfma = 'mfma' in kname
+    alg_bytes = n * (k + 1) * 8 + n * 8 + sum(len(t) for t in trajs) * 3 * 8
     roofline = {
-        'bound': 'mfma',
-        'pipe': 'fp64 vector FMA (v_fma_f64); the gfx950 f64 matrix peak is the same 78.6 TFLOP/s',
+        'bound': 'mfma' if is_mfma else 'valu',
+        'pipe': ('fp64 matrix pipe (v_mfma_f64_4x4x4_4b)' if is_mfma else
+                 'fp64 vector FMA issue (v_fma_f64 / v_fmac_f64_dpp); no MFMA in this kernel'),
         'kernel': kname,
-        'achieved': can / ksec / 1e12, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-        'frac': can / ksec / 1e12 / FP64_PEAK_TFLOPS,
-        'traffic': traffic,
-        'traffic_unit': 'bytes per launch (FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC, profiles/r01_hbm_traffic.json)',
-        'flops_basis': 'canonical F of SURVEY 8a (dense recursion on all N monomers) x evaluations per launch',
-        'flop_per_eval_canonical': can / n,
+        'achieved': exe / ksec / 1e12, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+        'frac': exe / ksec / 1e12 / FP64_PEAK_TFLOPS,
+        'flops_basis': 'operations the kernel executes: modal recursion on the reduced chain, frames actually run',
         'flop_per_eval_executed': exe / n,
-        'executed_achieved': exe / ksec / 1e12,
-        'executed_frac': exe / ksec / 1e12 / FP64_PEAK_TFLOPS,
+        'frames_executed_fraction': frames_frac,
         'kernel_ms': kernel_ms,
+        'traffic': traffic,
+        'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC passes, gfx950 correction applied; profiles/r02_hbm_traffic.json)',
+        'algorithmic_bytes_per_launch': alg_bytes,
+        'hbm_algorithmic_GBps': alg_bytes / ksec / 1e9,
+        'hbm_frac': alg_bytes / ksec / 1e9 / HBM_PEAK_GBS,
         'attainable_fma_peak': 51.5,
-        'attainable_note': 'register-resident v_fma_f64 loop measured on MI355X: 51.5 TFLOP/s at >= 2 waves/SIMD, 34.1 at one (profiles/r01_f64_rates.txt)',
-        'hbm_algorithmic_GBps': (n * (k + 1) * 8 + n * 8 + T * 3 * 8) / ksec / 1e9,
-        'hbm_frac': (n * (k + 1) * 8 + n * 8 + T * 3 * 8) / ksec / 1e9 / HBM_PEAK_GBS,
-        'note': ('path=%s runs the recursion in %d of %d modes (invariant-subspace reduction) and, on the modal '
-                 'path, in the eigenbasis of B (elementwise predict): frac > 1 means fewer operations were '
-                 'executed than the canonical count, executed_frac is the fraction of the fp64 peak the '
-                 'instructions actually issued reach') % (args.path, h.query(_lib.Q_NEFF), h.query(_lib.Q_N)),
+        'attainable_note': 'register-resident v_fma_f64 loop measured on MI355X: 51.5 TFLOP/s at >= 2 waves/SIMD (profiles/r01_f64_rates.txt)',
+        'flop_per_eval_canonical': can / n,
+        'canonical_equiv_frac': can / ksec / 1e12 / FP64_PEAK_TFLOPS,
+        'canonical_note': ('SURVEY 8a canonical F (dense recursion on all N monomers) / kernel time / peak: a SPEED-UP '
+                           'equivalent (the kernel runs %d of %d modes in the eigenbasis of B), not a utilisation'
+                           % (h.query(_lib.Q_NEFF), h.query(_lib.Q_N))),
     }
 
     result = {
         'metric': 'logL evaluations/sec (T=1000, 2-state) per AMIS batch',
         'value': value, 'unit': 'evals/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+        'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': args.scaling,
         'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-        'config': {'workload': f'configs[1]: {n} profile samples x 1 trajectory per GPU, T={T}, {args.states}-state '
-                               f'Rouse N=20 d=3 d*=1, k={k} switches, fp64',
-                   'samples_per_gpu': n, 'T': T, 'k': k, 'states': args.states, 'path': args.path,
-                   'collective': ('all_gather(float64[%d]) per step, %s' % (n, args.backend)) if world > 1 else 'none (1 GPU)'},
+        'config': {'workload': workload, 'samples_this_rank': n, 'samples_global': n_global, 'T': T, 'k': k,
+                   'states': args.states, 'path': args.path,
+                   'collective': ('all_gather(float64[%d]) per step, %s' % (pad, args.backend)) if world > 1 else 'none (1 GPU)'},
         'roofline': roofline,
     }
 
-    if rank == 0 and world == 1:
-        if not args.no_dense and args.path != 'dense':
-            ddt, dkms, dname = timed('dense', max(3, args.steps // 10), 1)
+    # ---- the seam: FixedkSampler.logL(ss, thetas), host arrays in, host array out ----------------------------
+    if traj_id is None:
+        model_for_sampler = bdist.ShardedModel(model) if (world > 1 and args.scaling == 'strong') else model
+        sampler = bild_amd.FixedkSampler(trajs[0], model_for_sampler, k=k, N=len(ss), max_fcomplete=0)
+        if world > 1 and args.scaling == 'strong':
+            # replicated AMIS loop: every rank passes the FULL batch, evaluates its shard, one all-gather
+            _, _, ss_full, thetas_full = build_workload(0, n_global, T, k, S=args.states)
+            seam_args = (ss_full, thetas_full)
+        else:
+            seam_args = (ss, thetas)
+        got = sampler.logL(*seam_args)
+        sdt, skms, _ = timed(lambda: sampler.logL(*seam_args), args.steps, min(args.warmup, 3))
+        result['api_seam'] = {
+            'what': 'FixedkSampler.logL(ss, thetas): host (N,k+1) float64 + int64 in, host (N,) float64 out, per step '
+                    '(bild/amis.py:717-739)',
+            'value': (n_global if args.scaling == 'strong' else n * world) * args.steps / sdt, 'unit': 'evals/s',
+            'ms_per_call': sdt / args.steps * 1e3, 'kernel_ms': skms,
+        }
+        step(args.path)
+        torch.cuda.synchronize()
+        if not (world > 1 and args.scaling == 'strong'):
+            result['api_seam']['max_abs_diff_vs_device_entry'] = float(np.max(np.abs(got - d_out[:n].cpu().numpy())))
+
+    if rank == 0 and world == 1 and args.scaling == 'weak':
+        if not args.no_secondary and args.path != 'dense':
+            reps = max(3, args.steps // 10)
+            ddt, dkms, dname = timed(lambda: step('dense'), reps, 1)
             dcan, dexe = _lib.flop_count(h, ts, n, path='dense')
             result['dense_path'] = {
-                'value': n * max(3, args.steps // 10) / ddt, 'unit': 'evals/s', 'kernel': dname, 'kernel_ms': dkms,
-                'achieved': dcan / (dkms * 1e-3) / 1e12, 'frac': dcan / (dkms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
-                'executed_frac': dexe / (dkms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                'what': 'BILD_PATH_DENSE on the reduced chain (C <- B C B + Sig every frame)',
+                'value': n * reps / ddt, 'unit': 'evals/s', 'kernel': dname, 'kernel_ms': dkms,
+                'bound': 'mfma' if 'mfma' in dname else 'valu',
+                'achieved': dexe / (dkms * 1e-3) / 1e12, 'frac': dexe / (dkms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
             }
-        if not args.no_dense and not args.no_reduce:
+        if not args.no_secondary and not args.no_reduce:
             # the reference's literal algorithm: all N monomers, C <- B C B + Sig every frame
             # (canonical flop count == executed flop count)
             a_ = model.arrays()
             h_full = _lib.ModelHandle(a_['B'], a_['G'], a_['Sig'], a_['M0'], a_['C0'], model.measurement, reduce=False)
-            ts_full = _lib.TrajSetHandle(h_full, [np.asarray(traj[:])], np.asarray(model.localization_error)[None, :])
-            reps = 3
-            _lib.kernel_timing(False)
-            for _ in range(1):
+            ts_full = _lib.TrajSetHandle(h_full, [np.asarray(trajs[0][:])], np.asarray(model.localization_error)[None, :])
+
+            def canon():
                 _lib.logl_segments_device(h_full, ts_full, n, k + 1, d_start.data_ptr(), d_state.data_ptr(), 0,
                                           d_out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream, path='dense')
-            _lib.kernel_timing(True)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                _lib.logl_segments_device(h_full, ts_full, n, k + 1, d_start.data_ptr(), d_state.data_ptr(), 0,
-                                          d_out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream, path='dense')
-            torch.cuda.synchronize()
-            cdt = time.perf_counter() - t0
-            _lib.kernel_timing(False)
-            ckms, claunches, cname = _lib.kernel_timing_read()
-            ckms /= max(claunches, 1)
+            cdt, ckms, cname = timed(canon, 3, 1)
             ccan, cexe = _lib.flop_count(h_full, ts_full, n, path='dense')
-            full_out = d_out.cpu().numpy().copy()
+            full_out = d_out[:n].cpu().numpy().copy()
             result['canonical_path'] = {
                 'what': 'dense path without reduction: the reference recursion itself on all %d monomers' % h_full.query(_lib.Q_N),
-                'value': n * reps / cdt, 'unit': 'evals/s', 'kernel': cname, 'kernel_ms': ckms,
-                'achieved': ccan / (ckms * 1e-3) / 1e12, 'unit_achieved': 'TFLOP/s fp64',
-                'frac': ccan / (ckms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                'value': n * 3 / cdt, 'unit': 'evals/s', 'kernel': cname, 'kernel_ms': ckms, 'bound': 'mfma' if 'mfma' in cname else 'valu',
+                'achieved': cexe / (ckms * 1e-3) / 1e12, 'unit_achieved': 'TFLOP/s fp64',
+                'frac': cexe / (ckms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
             }
             step(args.path)
             torch.cuda.synchronize()
-            result['canonical_path']['max_abs_diff_vs_default_path'] = float(np.max(np.abs(full_out - d_out.cpu().numpy())))
-        if args.host_buffers:
-            # PCIe-inclusive rate of the synchronous host entry point (never `value`)
-            for _ in range(2):
-                _lib.logl_segments(h, ts, seg_start, seg_state, path=args.path)
-            t0 = time.perf_counter()
-            reps = max(5, args.steps // 2)
-            for _ in range(reps):
-                _lib.logl_segments(h, ts, seg_start, seg_state, path=args.path)
-            result['host_buffers'] = {'value': n * reps / (time.perf_counter() - t0), 'unit': 'evals/s',
-                                      'note': 'bild_logl_segments: H2D profiles + launch + D2H results + sync per step'}
+            result['canonical_path']['max_abs_diff_vs_default_path'] = float(np.max(np.abs(full_out - d_out[:n].cpu().numpy())))
         if not args.no_cpu_baseline:
             base, ref_out = cpu_baseline(rank, n, T, k, args.states)
             result['cpu_baseline'] = base
@@ -309,6 +382,11 @@ def main():
             got = d_out[:len(ref_out)].cpu().numpy()
             result['parity_max_abs_diff_vs_cpu_baseline'] = float(np.max(np.abs(got - ref_out)))
             result['speedup_vs_cpu_baseline'] = value / base['value']
+            if args.cpu_allcores:
+                cores = len(os.sched_getaffinity(0))
+                allc, _ = cpu_baseline(rank, n, T, k, args.states, budget_s=10.0, procs=cores)
+                result['cpu_baseline_allcores'] = allc
+                result['speedup_vs_cpu_allcores'] = value / allc['value']
 
     if rank == 0:
         print(json.dumps(result))

@@ -19,6 +19,7 @@ OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_NOMEM = range(6)
 PATH_AUTO, PATH_DENSE, PATH_MODAL = 0, 1, 2
 PATHS = {'auto': PATH_AUTO, 'dense': PATH_DENSE, 'modal': PATH_MODAL}
 MODEL_NO_REDUCE = 1
+VALIDATE_DEVICE = 0x10
 
 Q_N, Q_D, Q_S, Q_MODAL_OK, Q_NP, Q_NEFF, Q_HAS_G = range(7)
 X_LAMBDA, X_SIGMA, X_Q, X_WQ, X_R, X_C0Q, X_V = range(7)
@@ -49,6 +50,9 @@ _SIGNATURES = {
     'bild_trajset_create': (ctypes.c_int, [_vp, ctypes.c_int, _ip, _dp, _dp, ctypes.POINTER(_vp)]),
     'bild_trajset_destroy': (ctypes.c_int, [_vp]),
     'bild_logl_segments': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, _ip, _ip, _ip, ctypes.c_uint, _dp]),
+    'bild_logl_st': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, _dp, _vp, _ip, ctypes.c_uint, _dp]),
+    'bild_logl_st_to_device': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, _dp, _vp, _ip, ctypes.c_uint, _vp, _vp]),
+    'bild_segments_from_st': (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, _ip, ctypes.c_int64, _dp, _vp, _ip, _ip]),
     'bild_logl_profiles': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int64, _ip, _ip, ctypes.c_uint, _dp]),
     'bild_logl_segments_device': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, _vp, _vp, _vp,
                                                  ctypes.c_uint, _vp, _vp]),
@@ -216,6 +220,46 @@ def logl_segments(model, ts, seg_start, seg_state, traj_id=None, path='auto'):
     return out
 
 
+def logl_st(model, ts, ss, thetas, traj_id=None, path='auto'):
+    """ the sampler's (s, theta) batch as it is: switch frames are computed natively (bild_logl_st) """
+    ss = f64(ss)
+    thetas = np.ascontiguousarray(thetas, dtype=np.int64)
+    if ss.ndim == 1:
+        ss, thetas = ss[None, :], thetas[None, :]
+    n, K1 = thetas.shape
+    assert ss.shape == (n, K1)
+    tid = None if traj_id is None else i32(traj_id)
+    out = np.empty(n, dtype=np.float64)
+    check(lib().bild_logl_st(model._h, ts._h, n, K1, dptr(ss), thetas.ctypes.data_as(_vp), iptr(tid), PATHS[path], dptr(out)))
+    return out
+
+
+def logl_st_to_device(model, ts, ss, thetas, d_out, traj_id=None, stream=0, path='auto'):
+    """ host (s, theta) batch in, results left in HBM at the raw device pointer `d_out`; asynchronous on `stream` """
+    ss = f64(ss)
+    thetas = np.ascontiguousarray(thetas, dtype=np.int64)
+    n, K1 = thetas.shape
+    assert ss.shape == (n, K1)
+    tid = None if traj_id is None else i32(traj_id)
+    check(lib().bild_logl_st_to_device(model._h, ts._h, n, K1, dptr(ss), thetas.ctypes.data_as(_vp), iptr(tid), PATHS[path],
+                                       _vp(stream) if stream else None, _vp(d_out)))
+
+
+def segments_from_st(ss, thetas, T, n_states):
+    """ native (s, theta) -> run-length segments (bild_segments_from_st); T: one length or one per sample """
+    ss = f64(ss)
+    thetas = np.ascontiguousarray(thetas, dtype=np.int64)
+    n, K1 = thetas.shape
+    assert ss.shape == (n, K1)
+    Ts = i32(np.atleast_1d(T))
+    assert len(Ts) in (1, n)
+    seg_start = np.empty((n, K1), dtype=np.int32)
+    seg_state = np.empty((n, K1), dtype=np.int32)
+    check(lib().bild_segments_from_st(n, K1, int(n_states), iptr(Ts), 0 if len(Ts) == 1 else 1, dptr(ss),
+                                      thetas.ctypes.data_as(_vp), iptr(seg_start), iptr(seg_state)))
+    return seg_start, seg_state
+
+
 def logl_profiles(model, ts, states, traj_id=None, path='auto'):
     states = i32(np.atleast_2d(states))
     n, ld = states.shape
@@ -225,10 +269,10 @@ def logl_profiles(model, ts, states, traj_id=None, path='auto'):
     return out
 
 
-def logl_segments_device(model, ts, n, K1, d_seg_start, d_seg_state, d_traj_id, d_out, stream=0, path='auto'):
-    """ raw device pointers (ints); asynchronous on `stream` """
+def logl_segments_device(model, ts, n, K1, d_seg_start, d_seg_state, d_traj_id, d_out, stream=0, path='auto', validate=False):
+    """ raw device pointers (ints); asynchronous on `stream` (validate=True: descriptors checked on the device first) """
     check(lib().bild_logl_segments_device(model._h, ts._h, n, K1, _vp(d_seg_start), _vp(d_seg_state),
-                                          _vp(d_traj_id) if d_traj_id else None, PATHS[path],
+                                          _vp(d_traj_id) if d_traj_id else None, PATHS[path] | (VALIDATE_DEVICE if validate else 0),
                                           _vp(stream) if stream else None, _vp(d_out)))
 
 

@@ -81,6 +81,33 @@ struct DeviceBuf {
     }
 };
 
+// page-locked host staging: copies to and from it are true asynchronous DMA transfers
+struct PinnedBuf {
+    void *ptr = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes)
+    {
+        if (bytes <= cap) return BILD_OK;
+        if (ptr) (void)hipHostFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 4 + 4096;
+        hipError_t e = hipHostMalloc(&ptr, want, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            ptr = nullptr;
+            return fail(BILD_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        }
+        cap = want;
+        return BILD_OK;
+    }
+    void release()
+    {
+        if (ptr) (void)hipHostFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+    }
+};
+
 // kernel timing (bench.py roofline leg)
 std::mutex g_time_mu;
 bool g_time_on = false;
@@ -120,7 +147,14 @@ struct bild_model {
     mutable int device = -1;
     mutable double *d_states[2] = {nullptr, nullptr};
     mutable double *d_tab[2] = {nullptr, nullptr};
-    mutable DeviceBuf ws_seg_start, ws_seg_state, ws_traj_id, ws_out, ws_partial;
+    // host-buffer entry points (one call at a time per model, call_mu): ONE packed device buffer
+    // [seg_start | seg_state | traj_id] filled by one copy out of pinned staging, results back through
+    // pinned staging, all on the model's own stream
+    mutable DeviceBuf ws_in, ws_out;
+    mutable PinnedBuf h_in, h_out;
+    mutable hipStream_t stream = nullptr;
+    mutable hipEvent_t h_in_event = nullptr; // completion of the last copy out of h_in that nobody waited for
+    mutable bool h_in_busy = false;
 };
 
 struct bild_trajset {
@@ -466,6 +500,8 @@ int ensure_device(const bild_model &m)
         HIP_TRY(hipMalloc((void **)&m.d_tab[mode], m.blob_tab[mode].size() * sizeof(double)));
         HIP_TRY(hipMemcpy(m.d_tab[mode], m.blob_tab[mode].data(), m.blob_tab[mode].size() * sizeof(double), hipMemcpyHostToDevice));
     }
+    HIP_TRY(hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&m.h_in_event, hipEventDisableTiming));
     m.device = dev;
     return BILD_OK;
 }
@@ -531,12 +567,12 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
     p.seg_state = d_seg_state;
     p.traj_id = d_traj_id;
     p.zeros = ts.d_zeros;
+    // d* > 1: one partial result per (sample, covariance chain), summed by a second kernel.  The buffer belongs to
+    // THIS call (stream-ordered allocation, released behind the reduction): launches of one model on different
+    // streams, or a host-buffer call beside a device-buffer call, share nothing.
     double *target = d_out;
     if (ts.dstar_max > 1) {
-        std::lock_guard<std::mutex> lk(m.mu);
-        rc = m.ws_partial.reserve((size_t)p.ntasks * sizeof(double));
-        if (rc) return rc;
-        target = (double *)m.ws_partial.ptr;
+        HIP_TRY(hipMallocAsync((void **)&target, (size_t)p.ntasks * sizeof(double), st));
     }
     p.out = target;
 
@@ -560,7 +596,10 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
               : fam == kModalTiles ? launch_logl_modal_mfma(m.NPm[kModal], p, (void *)st)
               : fam == kDenseTiles ? launch_logl_dense_mfma(m.NPm[kDense], p, (void *)st)
                                    : launch_logl(geom, mode, p, grid, lds, (void *)st);
-    if (lrc != 0) return fail(BILD_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
+    if (lrc != 0) {
+        if (ts.dstar_max > 1) (void)hipFreeAsync(target, st);
+        return fail(BILD_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
+    }
     if (timing) {
         HIP_TRY(hipEventRecord(e1, st));
         std::lock_guard<std::mutex> lk(g_time_mu);
@@ -569,8 +608,60 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
     }
     if (ts.dstar_max > 1) {
         lrc = launch_reduce_partials(target, d_out, n, ts.dstar_max, (void *)st);
+        (void)hipFreeAsync(target, st);
         if (lrc != 0) return fail(BILD_ERR_HIP, "reduce launch failed: %s", hipGetErrorString((hipError_t)lrc));
     }
+    return BILD_OK;
+}
+
+// Host buffers in, host buffer out.  `fill(h_start, h_state)` writes the n x K1 run-length segments straight into
+// pinned staging memory (and validates them: these indices drive device addressing); then ONE host-to-device copy of
+// the packed block [seg_start | seg_state | traj_id], the launch, one device-to-host copy of the results, one
+// synchronisation -- all on the model's own stream.
+template <typename Fill>
+int run_staged(const bild_model *m, const bild_trajset *ts, int64_t n, int K1, const int32_t *traj_id, unsigned flags,
+               double *out, double *d_out_user, hipStream_t st_user, Fill &&fill)
+{
+    int rc;
+    if (traj_id)
+        for (int64_t r = 0; r < n; ++r)
+            if (traj_id[r] < 0 || traj_id[r] >= ts->n_traj)
+                return fail(BILD_ERR_INVALID, "traj_id[%lld]=%d out of range", (long long)r, traj_id[r]);
+    std::lock_guard<std::mutex> call_lock(m->call_mu);
+    const size_t nseg = (size_t)n * K1;
+    const size_t in_bytes = (2 * nseg + (traj_id ? (size_t)n : 0)) * sizeof(int32_t);
+    // a previous call that left its results on the device may still be reading the staging block
+    if (m->h_in_busy) HIP_TRY(hipEventSynchronize(m->h_in_event));
+    m->h_in_busy = false;
+    {
+        std::lock_guard<std::mutex> lk(m->mu);
+        if ((rc = m->h_in.reserve(in_bytes))) return rc;
+        if ((rc = m->ws_in.reserve(in_bytes))) return rc;
+        if (!d_out_user) {
+            if ((rc = m->h_out.reserve((size_t)n * sizeof(double)))) return rc;
+            if ((rc = m->ws_out.reserve((size_t)n * sizeof(double)))) return rc;
+        }
+    }
+    int32_t *h_start = (int32_t *)m->h_in.ptr, *h_state = h_start + nseg, *h_tid = h_state + nseg;
+    if ((rc = fill(h_start, h_state))) return rc;
+    if (traj_id) std::memcpy(h_tid, traj_id, (size_t)n * sizeof(int32_t));
+    int32_t *d_start = (int32_t *)m->ws_in.ptr, *d_state = d_start + nseg, *d_tid = traj_id ? d_state + nseg : nullptr;
+    double *d_out = d_out_user ? d_out_user : (double *)m->ws_out.ptr;
+    hipStream_t st = d_out_user ? st_user : m->stream;
+    HIP_TRY(hipMemcpyAsync(d_start, h_start, in_bytes, hipMemcpyHostToDevice, st));
+    if (d_out_user) {
+        HIP_TRY(hipEventRecord(m->h_in_event, st));
+        m->h_in_busy = true;
+    }
+    rc = launch_batch(*m, *ts, n, K1, d_start, d_state, d_tid, flags, st, d_out);
+    if (rc) {
+        (void)hipStreamSynchronize(st);
+        return rc;
+    }
+    if (d_out_user) return BILD_OK; // results stay in HBM, ordered on the caller's stream
+    HIP_TRY(hipMemcpyAsync(m->h_out.ptr, d_out, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    std::memcpy(out, m->h_out.ptr, (size_t)n * sizeof(double));
     return BILD_OK;
 }
 
@@ -635,11 +726,13 @@ int bild_model_destroy(bild_model *m)
         if (m->d_states[mode]) (void)hipFree(m->d_states[mode]);
         if (m->d_tab[mode]) (void)hipFree(m->d_tab[mode]);
     }
-    m->ws_seg_start.release();
-    m->ws_seg_state.release();
-    m->ws_traj_id.release();
+    m->ws_in.release();
     m->ws_out.release();
-    m->ws_partial.release();
+    m->h_in.release();
+    m->h_out.release();
+    if (m->h_in_busy) (void)hipEventSynchronize(m->h_in_event);
+    if (m->h_in_event) (void)hipEventDestroy(m->h_in_event);
+    if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
     return BILD_OK;
 }
@@ -804,7 +897,24 @@ int bild_logl_segments_device(const bild_model *m, const bild_trajset *ts, int64
     if (rc) return rc;
     if (n == 0) return BILD_OK;
     if (!d_seg_start || !d_seg_state || !d_out) return fail(BILD_ERR_INVALID, "NULL device buffer");
-    return launch_batch(*m, *ts, n, K1, d_seg_start, d_seg_state, d_traj_id, flags, (hipStream_t)hip_stream, d_out);
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (flags & BILD_VALIDATE_DEVICE) {
+        // checked on the device, verdict read back BEFORE anything is launched: this variant of the call waits
+        int *d_err = nullptr;
+        int h_err[2] = {0, 0};
+        HIP_TRY(hipMallocAsync((void **)&d_err, 2 * sizeof(int), st));
+        HIP_TRY(hipMemsetAsync(d_err, 0, 2 * sizeof(int), st));
+        int lrc = launch_validate(d_seg_start, d_seg_state, d_traj_id, n, K1, m->S, ts->n_traj, d_err, (void *)st);
+        hipError_t ce = lrc == 0 ? hipMemcpyAsync(h_err, d_err, sizeof h_err, hipMemcpyDeviceToHost, st) : (hipError_t)lrc;
+        (void)hipFreeAsync(d_err, st);
+        if (ce != hipSuccess) return fail(BILD_ERR_HIP, "descriptor check failed to run: %s", hipGetErrorString(ce));
+        HIP_TRY(hipStreamSynchronize(st));
+        static const char *const what[] = {"", "traj_id out of range", "first segment does not start at frame 0",
+                                           "segment starts are decreasing", "state out of range"};
+        if (h_err[0] != 0)
+            return fail(BILD_ERR_INVALID, "device descriptors rejected: %s (e.g. sample %d)", what[h_err[0] & 7], h_err[1]);
+    }
+    return launch_batch(*m, *ts, n, K1, d_seg_start, d_seg_state, d_traj_id, flags, st, d_out);
 }
 
 int bild_logl_segments(const bild_model *m, const bild_trajset *ts, int64_t n, int K1, const int32_t *seg_start,
@@ -814,41 +924,100 @@ int bild_logl_segments(const bild_model *m, const bild_trajset *ts, int64_t n, i
     if (rc) return rc;
     if (n == 0) return BILD_OK;
     if (!seg_start || !seg_state || !out) return fail(BILD_ERR_INVALID, "NULL buffer");
-    // validate on the host: these indices drive device addressing
-    for (int64_t r = 0; r < n; ++r) {
-        const int tj = traj_id ? traj_id[r] : 0;
-        if (tj < 0 || tj >= ts->n_traj) return fail(BILD_ERR_INVALID, "traj_id[%lld]=%d out of range", (long long)r, tj);
-        if (seg_start[r * K1] != 0) return fail(BILD_ERR_INVALID, "seg_start[%lld][0] must be 0", (long long)r);
-        for (int i = 0; i < K1; ++i) {
-            const int sv = seg_state[r * K1 + i];
-            if (sv < 0 || sv >= m->S) return fail(BILD_ERR_INVALID, "state %d out of range at sample %lld", sv, (long long)r);
-            if (i > 0 && seg_start[r * K1 + i] < seg_start[r * K1 + i - 1])
-                return fail(BILD_ERR_INVALID, "segment starts of sample %lld are decreasing", (long long)r);
+    const int S = m->S;
+    return run_staged(m, ts, n, K1, traj_id, flags, out, nullptr, nullptr, [&](int32_t *h_start, int32_t *h_state) -> int {
+        for (int64_t r = 0; r < n; ++r) {
+            const int32_t *a = seg_start + r * K1, *b = seg_state + r * K1;
+            if (a[0] != 0) return fail(BILD_ERR_INVALID, "seg_start[%lld][0] must be 0", (long long)r);
+            for (int i = 0; i < K1; ++i) {
+                if (b[i] < 0 || b[i] >= S) return fail(BILD_ERR_INVALID, "state %d out of range at sample %lld", b[i], (long long)r);
+                if (i > 0 && a[i] < a[i - 1]) return fail(BILD_ERR_INVALID, "segment starts of sample %lld are decreasing", (long long)r);
+                h_start[r * K1 + i] = a[i];
+                h_state[r * K1 + i] = b[i];
+            }
+        }
+        return BILD_OK;
+    });
+}
+
+// The (s, theta) parametrisation of the sampler itself.  Switch frames as reference bild/amis.py:685-688 computes
+// them, in the same floating-point operations:  np.cumsum(s)[:-1] is a sequential sum, times (T - 1) is one
+// multiplication, floor, + 1.  No contraction of the multiply into the add: x86-64 baseline code has no fused
+// instruction, and the pragma keeps it that way on any other target (file scope: it covers the lambda below).
+#pragma clang fp contract(off)
+static int st_row(const double *s, const int64_t *th, int K1, int S, double Tm1, int64_t r, int32_t *a, int32_t *b)
+{
+    a[0] = 0;
+    double acc = 0.0;
+    int32_t prev = 0;
+    bool ok = true;
+    for (int i = 0; i < K1; ++i) {
+        ok &= (uint64_t)th[i] < (uint64_t)S;
+        b[i] = (int32_t)th[i];
+        if (i + 1 < K1) {
+            acc = acc + s[i];
+            const double pos = acc * Tm1;
+            // floor(pos) for 0 <= pos < 2^31 is the truncating conversion (one SSE2 instruction, no libm call);
+            // anything else -- negative, NaN, or beyond any trajectory -- is sorted out below
+            const bool in_range = pos >= 0.0 && pos < 2147483646.0;
+            const int32_t idx = in_range ? (int32_t)((int64_t)pos + 1) : (pos >= 2147483646.0 ? INT_MAX : -1);
+            ok &= idx >= prev;
+            prev = idx;
+            a[i + 1] = idx;
         }
     }
-    std::lock_guard<std::mutex> call_lock(m->call_mu);
-    const size_t segbytes = (size_t)n * K1 * sizeof(int32_t);
-    int32_t *d_start, *d_state, *d_tid = nullptr;
-    double *d_out;
-    {
-        std::lock_guard<std::mutex> lk(m->mu);
-        if ((rc = m->ws_seg_start.reserve(segbytes))) return rc;
-        if ((rc = m->ws_seg_state.reserve(segbytes))) return rc;
-        if ((rc = m->ws_out.reserve((size_t)n * sizeof(double)))) return rc;
-        if (traj_id && (rc = m->ws_traj_id.reserve((size_t)n * sizeof(int32_t)))) return rc;
-        d_start = (int32_t *)m->ws_seg_start.ptr;
-        d_state = (int32_t *)m->ws_seg_state.ptr;
-        d_out = (double *)m->ws_out.ptr;
-        if (traj_id) d_tid = (int32_t *)m->ws_traj_id.ptr;
+    if (ok) return BILD_OK;
+    for (int i = 0; i < K1; ++i)
+        if (th[i] < 0 || th[i] >= S)
+            return fail(BILD_ERR_INVALID, "state %lld out of range at sample %lld", (long long)th[i], (long long)r);
+    return fail(BILD_ERR_INVALID, "interval lengths of sample %lld are not non-negative finite numbers", (long long)r);
+}
+
+int bild_segments_from_st(int64_t n, int K1, int n_states, const int32_t *T, int64_t T_stride, const double *ss,
+                          const int64_t *thetas, int32_t *seg_start, int32_t *seg_state)
+{
+    if (n < 0 || K1 < 1 || n_states < 1) return fail(BILD_ERR_INVALID, "bad sizes");
+    if (n == 0) return BILD_OK;
+    if (!T || !ss || !thetas || !seg_start || !seg_state) return fail(BILD_ERR_INVALID, "NULL buffer");
+    for (int64_t r = 0; r < n; ++r) {
+        const int32_t Tr = T[r * T_stride];
+        if (Tr < 1) return fail(BILD_ERR_INVALID, "trajectory length %d < 1", Tr);
+        int rc = st_row(ss + r * K1, thetas + r * K1, K1, n_states, (double)(Tr - 1), r, seg_start + r * K1, seg_state + r * K1);
+        if (rc) return rc;
     }
-    HIP_TRY(hipMemcpy(d_start, seg_start, segbytes, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_state, seg_state, segbytes, hipMemcpyHostToDevice));
-    if (traj_id) HIP_TRY(hipMemcpy(d_tid, traj_id, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
-    rc = launch_batch(*m, *ts, n, K1, d_start, d_state, d_tid, flags, nullptr, d_out);
-    if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(nullptr));
-    HIP_TRY(hipMemcpy(out, d_out, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
     return BILD_OK;
+}
+
+static int logl_st_impl(const bild_model *m, const bild_trajset *ts, int64_t n, int K1, const double *ss, const int64_t *thetas,
+                        const int32_t *traj_id, unsigned flags, double *out, double *d_out, void *hip_stream)
+{
+    int rc = check_eval_args(m, ts, n, K1);
+    if (rc) return rc;
+    if (n == 0) return BILD_OK;
+    if (!ss || !thetas || (!out && !d_out)) return fail(BILD_ERR_INVALID, "NULL buffer");
+    const int S = m->S;
+    return run_staged(m, ts, n, K1, traj_id, flags, out, d_out, (hipStream_t)hip_stream, [&](int32_t *h_start, int32_t *h_state) -> int {
+        for (int64_t r = 0; r < n; ++r) {
+            const double Tm1 = (double)(ts->descs[traj_id ? traj_id[r] : 0].T - 1);
+            int rc2 = st_row(ss + r * K1, thetas + r * K1, K1, S, Tm1, r, h_start + r * K1, h_state + r * K1);
+            if (rc2) return rc2;
+        }
+        return BILD_OK;
+    });
+}
+
+int bild_logl_st(const bild_model *m, const bild_trajset *ts, int64_t n, int K1, const double *ss, const int64_t *thetas,
+                 const int32_t *traj_id, unsigned flags, double *out)
+{
+    if (!out) return fail(BILD_ERR_INVALID, "NULL buffer");
+    return logl_st_impl(m, ts, n, K1, ss, thetas, traj_id, flags, out, nullptr, nullptr);
+}
+
+int bild_logl_st_to_device(const bild_model *m, const bild_trajset *ts, int64_t n, int K1, const double *ss,
+                           const int64_t *thetas, const int32_t *traj_id, unsigned flags, void *hip_stream, double *d_out)
+{
+    if (!d_out) return fail(BILD_ERR_INVALID, "NULL device buffer");
+    return logl_st_impl(m, ts, n, K1, ss, thetas, traj_id, flags, nullptr, d_out, hip_stream);
 }
 
 int bild_logl_profiles(const bild_model *m, const bild_trajset *ts, int64_t n, int64_t ld, const int32_t *states,

@@ -1,0 +1,26 @@
+// Host-only build for the sanitizers (make asan): the kernel launchers of the .hip files, which this build does not
+// contain.  The sanitizer run happens on a machine without a GPU, where no evaluation gets as far as a launch
+// (bild_trajset_create fails with BILD_ERR_NO_DEVICE first); the geometry tables are host code and are duplicated here
+// only as far as packing needs them (padded_rows), with the same values as kernels.hip.
+#include "common.h"
+
+namespace bild {
+int padded_rows(int n)
+{
+    static const int rows[] = {4, 8, 10, 12, 16, 20, 24, 28, 32};
+    for (int r : rows)
+        if (r >= n) return r;
+    return 0;
+}
+bool geometry_for(int, int, int64_t, int, Geometry *) { return false; }
+const char *kernel_name(const Geometry &, int) { return "none"; }
+int launch_logl(const Geometry &, int, const KParams &, int, size_t, void *) { return 1; }
+int launch_reduce_partials(const double *, double *, int64_t, int, void *) { return 1; }
+int launch_validate(const int32_t *, const int32_t *, const int32_t *, int64_t, int, int, int, int *, void *) { return 1; }
+bool dense_mfma_supported(int NP) { return NP % 4 == 0 && NP >= 4 && NP <= 24; }
+int launch_logl_dense_mfma(int, const KParams &, void *) { return 1; }
+bool modal_mfma_supported(int NP) { return NP == 36 || NP == 40; }
+int launch_logl_modal_mfma(int, const KParams &, void *) { return 1; }
+size_t wide_lds_bytes(int) { return 0; }
+int launch_logl_wide(int, const KParams &, int, void *) { return 1; }
+} // namespace bild

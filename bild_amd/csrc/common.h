@@ -1,5 +1,6 @@
 // Shared host/device definitions for the Rouse Kalman-filter log-likelihood kernels.
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 namespace bild {
@@ -78,6 +79,8 @@ constexpr int group_image_doubles(int NP) { return (NP + kDMax) * NP; }
 // host-callable launchers implemented in kernels.hip
 int launch_logl(const Geometry &g, int mode, const KParams &p, int grid, size_t lds_bytes, void *stream);
 int launch_reduce_partials(const double *partial, double *out, int64_t n, int dstar_max, void *stream);
+int launch_validate(const int32_t *seg_start, const int32_t *seg_state, const int32_t *traj_id, int64_t n, int K1, int S,
+                    int n_traj, int *d_err, void *stream);
 // smallest compiled row count >= n_rows, or 0
 int padded_rows(int n_rows);
 // launch geometry for `ntasks` recursions of a chain padded to NP rows, each with up to `means` mean vectors

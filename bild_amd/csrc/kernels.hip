@@ -69,6 +69,43 @@ __device__ __forceinline__ double block_sum16(double v, double add)
     return __builtin_amdgcn_mfma_f64_4x4x4f64(rows, 1.0, add, 0, 0, 0);
 }
 
+// ROW layout: a task occupies one 16-lane row of the wavefront and lane j of the row owns column j of [C | M].
+// gfx950 lets a double-precision VOP2 instruction read its first operand through DPP with the row_newbcast
+// controls (lane I of the row broadcast to all 16 lanes), so "acc += x[lane I] * w" is ONE instruction and the
+// all-gather of C w through LDS (a write, a wave barrier, NP/2 reads and their latency) disappears from the
+// frame loop.  hipcc does not fold a v_mov_b64_dpp into the FMA and does not pad the hazards of an asm
+// statement: a DPP source needs two wait states after the VALU instruction that wrote it (dpp_ready).
+template <int I>
+__device__ __forceinline__ void fmac_bcast(double &acc, double x, double w)
+{
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(w), "n"(I));
+}
+// orders every later reader of x behind two wait states after its producer
+__device__ __forceinline__ void dpp_ready(double &x) { asm volatile("s_nop 1" : "+v"(x)); }
+
+template <int NP, int I = 0>
+struct RowOps {
+    // sa += sum over even i of x[lane i] w[i], sb likewise over odd i (the order of the packed layouts)
+    static __device__ __forceinline__ void dot(double &sa, double &sb, double x, const double (&w)[NP])
+    {
+        fmac_bcast<I>(sa, x, w[I]);
+        fmac_bcast<I + 1>(sb, x, w[I + 1]);
+        RowOps<NP, I + 2>::dot(sa, sb, x, w);
+    }
+    // col[i] += x[lane i] * c
+    static __device__ __forceinline__ void rank1(double (&col)[NP], double x, double c)
+    {
+        fmac_bcast<I>(col[I], x, c);
+        fmac_bcast<I + 1>(col[I + 1], x, c);
+        RowOps<NP, I + 2>::rank1(col, x, c);
+    }
+};
+template <int NP>
+struct RowOps<NP, NP> {
+    static __device__ __forceinline__ void dot(double &, double &, double, const double (&)[NP]) {}
+    static __device__ __forceinline__ void rank1(double (&)[NP], double, double) {}
+};
+
 // log() is needed once per task; out of line, so that its polynomial constants are not hoisted
 // out of the task loop into registers the frame loop then has to spill around.
 __device__ __attribute__((noinline)) double log_once(double x) { return log(x); }
@@ -127,7 +164,9 @@ __device__ __forceinline__ void matvec_to_lds(XPtr X, const Cols<NP, CPL> &in, d
 
 // FLAVOR selects what the frame loop has to carry:
 //   0: external force (G != 0) and missing frames   1: missing frames   2: neither (every frame valid)
-template <int NP, int CPL, int G, int W, int OCC, int MODE, int FLAVOR>
+// LAY: 0 packed groups of G consecutive lanes; 1 a group is a 16-lane block of the f64 4x4x4 matrix instruction
+// (S as a block sum on the matrix pipe); 2 a group is a 16-lane row, cross-lane operands by DPP row broadcast
+template <int NP, int CPL, int G, int W, int OCC, int LAY, int MODE, int FLAVOR>
 __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
 {
     constexpr bool HASG = FLAVOR == 0;
@@ -137,7 +176,9 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
     constexpr int GPW = 64 / G;          // groups (= tasks in flight) per wavefront
     // block layout: a group is one 16-lane block of the f64 4x4x4 matrix instruction (lanes that share
     // bits 2-3), so that S = s2 + w.(Cw) is a block sum on the matrix pipe
-    constexpr bool BLK = (G == 16 && CPL == 1);
+    constexpr bool BLK = LAY == 1;
+    constexpr bool ROW = LAY == 2;
+    static_assert(LAY == 0 || (G == 16 && CPL == 1), "block / row layouts: 16 lanes per task, one column per lane");
     constexpr int MS = table_stride(NP); // LDS matrix stride
     constexpr int SB = StateBlock::size(NP);
     static_assert(NP % 2 == 0, "rows are read in pairs");
@@ -152,7 +193,7 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
     const int lane = tid & 63;
     const int wv = tid >> 6;
     const int grp = BLK ? ((lane >> 2) & 3) : lane / G;
-    const int gl = BLK ? ((lane & 3) | ((lane >> 4) << 2)) : lane - grp * G;
+    const int gl = BLK ? ((lane & 3) | ((lane >> 4) << 2)) : lane - grp * G; // ROW: lane / 16, lane % 16
 
     // Matrix tables live in LDS for the whole kernel: the dense propagators are needed every frame,
     // and a modal basis change walks its matrix row by row in a dependent loop -- from L2 that was
@@ -300,6 +341,23 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
                     a1 = fma(wq[i + 1], col.v[q][i + 1], a1);
                 }
                 ev[q] = (a0 + a1) - xv[q]; // covariance column: (C w)_c ; mean column: -(x - w.M)
+            }
+            if constexpr (ROW) {
+                // C w is never gathered: lane i of the row holds (C w)_i in ev and every use reads it by row broadcast
+                dpp_ready(ev[0]);
+                double sa = s2, sb2 = 0.0;
+                RowOps<NP>::dot(sa, sb2, ev[0], wq);
+                const double Sv = sa + sb2;
+                double Sinv = __builtin_amdgcn_rcp(Sv);
+                Sinv = fma(fma(-Sv, Sinv, 1.0), Sinv, Sinv);
+                Sinv = fma(fma(-Sv, Sinv, 1.0), Sinv, Sinv);
+                const double coef = ev[0] * Sinv;
+                accq[0] = fma(ev[0], coef, accq[0]);
+                RowOps<NP>::rank1(col.v[0], ev[0], -coef); // col[i] += (C w)_i * (-coef) = fma(-coef, cw[i], col[i])
+                int ex;
+                P = frexp(P * Sv, &ex);
+                E += ex;
+                return;
             }
             // every lane publishes (no exec masking): mean / spare columns land behind the NP
             // gathered entries (cidx < CPL*G <= group image size)
@@ -478,7 +536,26 @@ __global__ void reduce_partials_kernel(const double *__restrict__ partial, doubl
     out[r] = tot;
 }
 
-template <int NP, int CPL, int G, int W, int OCC>
+// Optional check of device-resident descriptors (BILD_VALIDATE_DEVICE): the indices below drive LDS and HBM
+// addressing in the likelihood kernels.  err[0] = first kind of violation seen (1 traj_id, 2 first start, 3 order of
+// starts, 4 state), err[1] = a sample that shows it.
+__global__ void validate_kernel(const int32_t *__restrict__ seg_start, const int32_t *__restrict__ seg_state,
+                                const int32_t *__restrict__ traj_id, int64_t n, int K1, int S, int n_traj, int *err)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    int bad = 0;
+    if (traj_id && (traj_id[r] < 0 || traj_id[r] >= n_traj)) bad = 1;
+    const int32_t *a = seg_start + r * K1, *b = seg_state + r * K1;
+    if (!bad && a[0] != 0) bad = 2;
+    for (int i = 0; i < K1 && !bad; ++i) {
+        if (i > 0 && a[i] < a[i - 1]) bad = 3;
+        else if (b[i] < 0 || b[i] >= S) bad = 4;
+    }
+    if (bad && atomicCAS(err, 0, bad) == 0) err[1] = (int)(r < INT_MAX ? r : INT_MAX);
+}
+
+template <int NP, int CPL, int G, int W, int OCC, int LAY>
 int launch_geom(int mode, const KParams &p, int grid, size_t lds, hipStream_t st)
 {
     constexpr int kThreads = 64 * W;
@@ -494,13 +571,13 @@ int launch_geom(int mode, const KParams &p, int grid, size_t lds, hipStream_t st
     // (and trajectories without a single missing frame out of the masked ones)
     const int flavor = p.has_G ? 0 : (p.all_valid ? 2 : 1);
     if (mode == kModal) {
-        if (flavor == 0) return go(logl_kernel<NP, CPL, G, W, OCC, kModal, 0>);
-        if (flavor == 1) return go(logl_kernel<NP, CPL, G, W, OCC, kModal, 1>);
-        return go(logl_kernel<NP, CPL, G, W, OCC, kModal, 2>);
+        if (flavor == 0) return go(logl_kernel<NP, CPL, G, W, OCC, LAY, kModal, 0>);
+        if (flavor == 1) return go(logl_kernel<NP, CPL, G, W, OCC, LAY, kModal, 1>);
+        return go(logl_kernel<NP, CPL, G, W, OCC, LAY, kModal, 2>);
     }
-    if (flavor == 0) return go(logl_kernel<NP, CPL, G, W, OCC, kDense, 0>);
-    if (flavor == 1) return go(logl_kernel<NP, CPL, G, W, OCC, kDense, 1>);
-    return go(logl_kernel<NP, CPL, G, W, OCC, kDense, 2>);
+    if (flavor == 0) return go(logl_kernel<NP, CPL, G, W, OCC, LAY, kDense, 0>);
+    if (flavor == 1) return go(logl_kernel<NP, CPL, G, W, OCC, LAY, kDense, 1>);
+    return go(logl_kernel<NP, CPL, G, W, OCC, LAY, kDense, 2>);
 }
 
 // (id, rows, columns per lane, lanes per group, waves per workgroup, min waves per SIMD, paths);
@@ -527,34 +604,44 @@ int launch_geom(int mode, const KParams &p, int grid, size_t lds, hipStream_t st
 //    and vector pipes share their FMA throughput, so only the redundancy of the per-lane S chain is saved.
 //    Not selected automatically: its S is summed in another order, and with it the results of one profile
 //    would differ in the last bits between batch sizes (all other geometries of an NP agree bit for bit).
-// last field: which paths may select the geometry automatically (1 = dense, 2 = modal, 3 = both).
+//  * NP = 10 / 12, one column per lane, G = 16, row layout (ids 21 / 22): a task is one 16-lane row and every use of
+//    (C w)_i reads lane i of the row by DPP row broadcast inside the FMA itself (v_fmac_f64_dpp ... row_newbcast) --
+//    no LDS all-gather in the frame loop, 20 registers less.  Same operations in the same order as the packed
+//    layouts, hence bit-identical results (checked: max |diff| = 0 against (1, 13) on every batch size tried).
+//    10 000 x T=1000: 485 -> 448 us; a lone wave (3 000 tasks) 285 -> 237 us; with missing frames 522 -> 484 us
+//    (profiles/r02_row_layout.txt).  Listed before the packed geometry with the same number of tasks per wave, so the
+//    modal path picks it whenever three mean vectors are needed; with fewer, (1, 11) / (1, 12) carry 5 tasks per wave.
+// seventh field: layout (0 packed, 1 matrix-instruction block, 2 row); last field: which paths may select the geometry
+// automatically (1 = dense, 2 = modal, 3 = both).
 // The dense recursion is FMA-bound with one LDS operand feeding 2*CPL FMAs, so it wants several
 // columns per lane where the modal one wants a single column.
 #define BILD_GEOMETRIES(X)     \
-    X(0, 4, 1, 7, 4, 3, 3)     \
-    X(1, 4, 2, 4, 4, 2, 3)     \
-    X(17, 8, 1, 9, 4, 3, 3)    \
-    X(18, 8, 1, 10, 4, 3, 3)   \
-    X(2, 8, 1, 11, 4, 3, 3)    \
-    X(19, 10, 1, 11, 4, 3, 3)  \
-    X(20, 10, 1, 12, 4, 3, 3)  \
-    X(3, 10, 1, 13, 4, 3, 3)   \
-    X(4, 10, 2, 7, 4, 2, 3)    \
-    X(5, 12, 1, 15, 4, 2, 3)   \
-    X(6, 12, 2, 8, 4, 2, 3)    \
-    X(7, 16, 1, 19, 4, 2, 2)   \
-    X(8, 16, 3, 7, 4, 1, 1)    \
-    X(9, 20, 1, 23, 4, 2, 2)   \
-    X(10, 20, 2, 12, 4, 1, 1)  \
-    X(11, 20, 3, 8, 4, 1, 1)   \
-    X(12, 24, 1, 27, 4, 1, 3)  \
-    X(13, 28, 1, 31, 4, 1, 3)  \
-    X(14, 32, 1, 35, 4, 1, 3)  \
-    X(15, 10, 1, 16, 4, 3, 0)  \
-    X(16, 12, 1, 16, 4, 2, 0)
+    X(0, 4, 1, 7, 4, 3, 0, 3)     \
+    X(1, 4, 2, 4, 4, 2, 0, 3)     \
+    X(17, 8, 1, 9, 4, 3, 0, 3)    \
+    X(18, 8, 1, 10, 4, 3, 0, 3)   \
+    X(2, 8, 1, 11, 4, 3, 0, 3)    \
+    X(19, 10, 1, 11, 4, 3, 0, 3)  \
+    X(20, 10, 1, 12, 4, 3, 0, 3)  \
+    X(21, 10, 1, 16, 4, 3, 2, 2)  \
+    X(3, 10, 1, 13, 4, 3, 0, 3)   \
+    X(4, 10, 2, 7, 4, 2, 0, 3)    \
+    X(22, 12, 1, 16, 4, 2, 2, 2)  \
+    X(5, 12, 1, 15, 4, 2, 0, 3)   \
+    X(6, 12, 2, 8, 4, 2, 0, 3)    \
+    X(7, 16, 1, 19, 4, 2, 0, 2)   \
+    X(8, 16, 3, 7, 4, 1, 0, 1)    \
+    X(9, 20, 1, 23, 4, 2, 0, 2)   \
+    X(10, 20, 2, 12, 4, 1, 0, 1)  \
+    X(11, 20, 3, 8, 4, 1, 0, 1)   \
+    X(12, 24, 1, 27, 4, 1, 0, 3)  \
+    X(13, 28, 1, 31, 4, 1, 0, 3)  \
+    X(14, 32, 1, 35, 4, 1, 0, 3)  \
+    X(15, 10, 1, 16, 4, 3, 1, 0)  \
+    X(16, 12, 1, 16, 4, 2, 1, 0)
 
 constexpr Geometry kGeoms[] = {
-#define X(ID, NP, CPL, G, W, OCC, MODES) {NP, CPL, G, W, OCC, ID, MODES},
+#define X(ID, NP, CPL, G, W, OCC, LAY, MODES) {NP, CPL, G, W, OCC, ID, MODES},
     BILD_GEOMETRIES(X)
 #undef X
 };
@@ -612,12 +699,21 @@ int launch_logl(const Geometry &g, int mode, const KParams &p, int grid, size_t 
 {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     switch (g.id) {
-#define X(ID, NP, CPL, G, W, OCC, MODES) \
-    case ID: return launch_geom<NP, CPL, G, W, OCC>(mode, p, grid, lds, st);
+#define X(ID, NP, CPL, G, W, OCC, LAY, MODES) \
+    case ID: return launch_geom<NP, CPL, G, W, OCC, LAY>(mode, p, grid, lds, st);
         BILD_GEOMETRIES(X)
 #undef X
     default: return -1;
     }
+}
+
+int launch_validate(const int32_t *seg_start, const int32_t *seg_state, const int32_t *traj_id, int64_t n, int K1, int S,
+                    int n_traj, int *d_err, void *stream)
+{
+    const int bs = 256;
+    hipLaunchKernelGGL(validate_kernel, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, reinterpret_cast<hipStream_t>(stream),
+                       seg_start, seg_state, traj_id, n, K1, S, n_traj, d_err);
+    return (int)hipGetLastError();
 }
 
 int launch_reduce_partials(const double *partial, double *out, int64_t n, int dstar_max, void *stream)

@@ -74,18 +74,41 @@ class ShardedModel:
     and ONE all-gather per AMIS step gives every rank the full log-likelihood vector, from which all
     ranks form identical weights and refit identical proposals (reference bild/amis.py:843-854).
 
+    With the RCCL backend the shard's results never leave HBM before the collective: the kernel writes them into
+    a device buffer (`MultiStateRouse.logL_st_batch_to_device`), that buffer is all-gathered on the same stream,
+    and the gathered vector is copied to the host ONCE.  With gloo (CPU rehearsal) the shard comes back through the
+    host entry and is gathered there.
+
     Wraps any model offering ``logL_st_batch``; everything else is forwarded.  With
     ``torch.distributed`` not initialised (or world size 1) it is a transparent pass-through.
+    The process group is not part of the pickled state (a copy talks to the default group).
     """
 
-    def __init__(self, model, group=None, device=None):
+    def __init__(self, model, group=None, device=None, collective_at_world1=False):
         self._model = model
         self._group = group
+        self._collective_at_world1 = collective_at_world1   # tests: run the sharded path on a single rank too
         self._device = device  # where to stage the gathered vector: None -> cuda for nccl, cpu for gloo
+        self._buffers = None   # (local, gathered) device tensors, grown on demand
         self.transitions = model.transitions
+        self.host_copies = 0   # device -> host copies made by logL_st_batch (tests assert one per step)
 
     def __getattr__(self, name):
+        # only reached for attributes that are not set on the wrapper itself.  While unpickling / copying the
+        # instance exists before its __dict__ does: never look up '_model' through here (it would recurse), and
+        # leave dunder lookups (__setstate__, __deepcopy__, ...) to the default machinery.
+        if name.startswith('__') or '_model' not in self.__dict__:
+            raise AttributeError(name)
         return getattr(self._model, name)
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state['_group'] = None
+        state['_buffers'] = None
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
 
     def _world(self):
         import torch.distributed as dist
@@ -93,24 +116,43 @@ class ShardedModel:
             return 1, 0
         return dist.get_world_size(self._group), dist.get_rank(self._group)
 
+    @staticmethod
+    def _initialised():
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized()
+
     def logL(self, profile, traj):
         return self._model.logL(profile, traj)
 
     def logL_st_batch(self, ss, thetas, traj):
         world, rank = self._world()
-        if world == 1:
+        if world == 1 and not (self._collective_at_world1 and self._initialised()):
             return self._model.logL_st_batch(ss, thetas, traj)
         import torch
         import torch.distributed as dist
         n = len(thetas)
         bounds = [shard_bounds(n, world, r) for r in range(world)]
+        sizes = [b - a for a, b in bounds]
         lo, hi = bounds[rank]
-        local = np.asarray(self._model.logL_st_batch(ss[lo:hi], thetas[lo:hi], traj), dtype=np.float64) if hi > lo \
-            else np.empty(0)
         device = self._device
         if device is None:
             device = 'cuda' if dist.get_backend(self._group) == 'nccl' else 'cpu'
-        full = all_gather_logl_ragged(torch.from_numpy(local).to(device), [b - a for a, b in bounds], self._group)
+        if str(device).startswith('cuda') and hasattr(self._model, 'logL_st_batch_to_device'):
+            m = max(sizes)
+            if self._buffers is None or self._buffers[0].numel() < m:
+                self._buffers = (torch.zeros(m, dtype=torch.float64, device=device),
+                                 torch.empty(m * world, dtype=torch.float64, device=device))
+            local, gathered = self._buffers[0][:m], self._buffers[1][:m * world]
+            if hi > lo:
+                self._model.logL_st_batch_to_device(ss[lo:hi], thetas[lo:hi], traj, local.data_ptr(),
+                                                    stream=torch.cuda.current_stream().cuda_stream)
+            dist.all_gather_into_tensor(gathered, local, group=self._group)      # same stream: ordered behind the kernel
+            host = gathered.cpu().numpy()                                        # the one device -> host copy of the step
+            self.host_copies += 1
+            return np.concatenate([host[r * m:r * m + sizes[r]] for r in range(world)])
+        local = np.asarray(self._model.logL_st_batch(ss[lo:hi], thetas[lo:hi], traj), dtype=np.float64) if hi > lo \
+            else np.empty(0)
+        full = all_gather_logl_ragged(torch.from_numpy(local).to(device), sizes, self._group)
         return full.cpu().numpy()
 
 

@@ -19,7 +19,7 @@ import numpy as np
 
 from . import _lib
 from . import rouse
-from .profiles import Loopingprofile, segments_from_st, segments_from_states
+from .profiles import Loopingprofile, segments_from_states
 from .trajectory import Trajectory, as_array
 
 
@@ -187,22 +187,37 @@ class MultiStateRouse(MultiStateModel):
         Device-resident set of trajectories (uploaded once, reused across AMIS steps).
 
         trajs : a trajectory or a list of trajectories
+
+        The cache is keyed by the IDENTITY of the trajectory objects (plus the address and shape of their data
+        and the localization errors in force), never by their contents: a lookup costs microseconds however
+        long the trajectories are.  Data changed in place are not noticed -- call `invalidate()` after doing that.
         """
-        if not isinstance(trajs, (list, tuple)):
-            trajs = [trajs]
-        noises = [np.asarray(self._get_noise(t), dtype=np.float64) for t in trajs]
-        arrs = [as_array(t) for t in trajs]
-        key = tuple((id(t), a.shape, a.tobytes() if a.size <= 4096 else hash(a.tobytes()), n.tobytes())
-                    for t, a, n in zip(trajs, arrs, noises))
-        ts = self._trajsets.get(key)
-        if ts is None:
-            ts = _lib.TrajSetHandle(self.handle(), arrs, np.stack(noises))
-            self._trajsets[key] = ts
-            while len(self._trajsets) > 8:
-                self._trajsets.popitem(last=False)
-        else:
-            self._trajsets.move_to_end(key)
+        single = not isinstance(trajs, (list, tuple))
+        items = (trajs,) if single else tuple(trajs)
+        key = tuple(map(id, items))
+        hit = self._trajsets.get(key)
+        if hit is not None:
+            ts, kept, prints = hit
+            if all(a is b for a, b in zip(kept, items)) and prints == self._fingerprints(items):
+                self._trajsets.move_to_end(key)
+                return ts
+        arrs = [as_array(t) for t in items]
+        noises = [np.asarray(self._get_noise(t), dtype=np.float64) for t in items]
+        ts = _lib.TrajSetHandle(self.handle(), arrs, np.stack(noises))
+        self._trajsets[key] = (ts, items, self._fingerprints(items))   # `items` keeps the objects (and their ids) alive
+        while len(self._trajsets) > 8:
+            self._trajsets.popitem(last=False)
         return ts
+
+    def _fingerprints(self, items):
+        out = []
+        for t in items:
+            a = t[:]
+            if isinstance(a, np.ndarray):
+                out.append((a.__array_interface__['data'][0], a.shape, np.asarray(self._get_noise(t)).tobytes()))
+            else:
+                out.append((None, len(t), np.asarray(self._get_noise(t)).tobytes()))
+        return out
 
     # ------------------------------------------------------------------ likelihood
     def logL(self, profile, traj):
@@ -229,8 +244,14 @@ class MultiStateRouse(MultiStateModel):
         One AMIS batch in (s, theta) parametrisation: what reference
         ``FixedkSampler.logL(ss, thetas)`` (bild/amis.py:717-739) computes with a Python loop.
         """
-        seg_start, seg_state = segments_from_st(ss, thetas, len(traj))
-        return _lib.logl_segments(self.handle(), self.trajset(traj), seg_start, seg_state, path=self.path)
+        return _lib.logl_st(self.handle(), self.trajset(traj), ss, thetas, path=self.path)
+
+    def logL_st_batch_to_device(self, ss, thetas, traj, d_out, stream=0):
+        """
+        Same batch, results left in HBM at the raw device pointer ``d_out`` (float64[len(thetas)]), asynchronous on
+        the HIP stream ``stream``: what `dist.ShardedModel` feeds into the all-gather of a multi-GPU AMIS step.
+        """
+        _lib.logl_st_to_device(self.handle(), self.trajset(traj), ss, thetas, d_out, stream=stream, path=self.path)
 
     def logL_st(self, s, theta, traj):
         """ the per-sample hook the reference sampler prefers when present (bild/amis.py:734-736) """

@@ -46,6 +46,12 @@ typedef enum bild_status {
                               (pyx:220-241)                                               */
 #define BILD_PATH_MODAL 2u /* same recursion carried in each state's eigenbasis of B      */
 
+/* bild_logl_segments_device only: check the device-resident descriptors with a small kernel first (traj_id range,
+ * first start 0, non-decreasing starts, states < S) and refuse the batch with BILD_ERR_INVALID instead of letting a bad
+ * index drive an out-of-range access.  The verdict has to be read back, so with this flag the call WAITS for the stream
+ * once before launching.  Without it the device entry trusts its input (the host-buffer entries always validate). */
+#define BILD_VALIDATE_DEVICE 0x10u
+
 /* bild_model_create flags */
 #define BILD_MODEL_NO_REDUCE 1u /* keep all N modes: skip the invariant-subspace reduction */
 
@@ -148,6 +154,29 @@ int bild_logl_segments(const bild_model *m, const bild_trajset *ts, int64_t n, i
                        const int32_t *seg_start, const int32_t *seg_state,
                        const int32_t *traj_id, unsigned flags, double *out);
 
+/* The sampler's own parametrisation, i.e. the arguments of FixedkSampler.logL(ss, thetas) (bild/amis.py:717-739)
+ * as they are: ss (n x K1 float64, rows on the simplex), thetas (n x K1 int64).  The switch frames are computed here
+ * exactly as FixedkSampler.st2profile does (bild/amis.py:685-688: sequential cumsum, times (T-1), floor, +1; T is the
+ * length of the sample's trajectory), written straight into pinned staging memory and shipped with one copy.
+ * Rows with a negative or non-finite entry are refused (BILD_ERR_INVALID).  Host buffers, synchronous. */
+int bild_logl_st(const bild_model *m, const bild_trajset *ts, int64_t n, int K1,
+                 const double *ss, const int64_t *thetas, const int32_t *traj_id,
+                 unsigned flags, double *out);
+
+/* Same input, but the n results stay in HBM: d_out (device, n doubles) is written asynchronously on `hip_stream`
+ * (a hipStream_t, NULL = default stream), nothing is copied back and nothing is waited for.  This is what a
+ * multi-GPU AMIS step uses: the shard's results go straight into the all-gather (dist.ShardedModel). */
+int bild_logl_st_to_device(const bild_model *m, const bild_trajset *ts, int64_t n, int K1,
+                           const double *ss, const int64_t *thetas, const int32_t *traj_id,
+                           unsigned flags, void *hip_stream, double *d_out);
+
+/* The conversion alone (host only, no GPU): FixedkSampler.st2profile's switch frames (bild/amis.py:685-693) as
+ * run-length segments.  Sample r belongs to a trajectory of T[r * T_stride] frames (T_stride 0: one length for all).
+ * seg_start / seg_state: n x K1 int32 out. */
+int bild_segments_from_st(int64_t n, int K1, int n_states, const int32_t *T, int64_t T_stride,
+                          const double *ss, const int64_t *thetas,
+                          int32_t *seg_start, int32_t *seg_state);
+
 /* expanded profiles (MSRouse_logL semantics, pyx:95-98): states is n rows of length
  * ld >= max T, row r holds T[traj_id[r]] valid entries.  Run-length encoded on the host,
  * then as above. */
@@ -157,7 +186,9 @@ int bild_logl_profiles(const bild_model *m, const bild_trajset *ts, int64_t n, i
 
 /* device buffers in, device buffer out; asynchronous on `hip_stream` (a hipStream_t, or
  * NULL for the default stream).  This is the entry point timed by bench.py: nothing
- * crosses PCIe.  d_out must hold n doubles. */
+ * crosses PCIe.  d_out must hold n doubles.  Re-entrant: concurrent launches of one model on
+ * different streams share no scratch (partial results of d* > 1 live in a per-call, stream-ordered
+ * allocation).  The descriptors are NOT validated unless BILD_VALIDATE_DEVICE is set in `flags`. */
 int bild_logl_segments_device(const bild_model *m, const bild_trajset *ts, int64_t n, int K1,
                               const int32_t *d_seg_start, const int32_t *d_seg_state,
                               const int32_t *d_traj_id, unsigned flags, void *hip_stream,

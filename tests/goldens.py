@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def names():
     """ the kernel-level goldens (the AMIS / ChoiceSampler fixtures live beside them under their own prefixes) """
     all_names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(HERE, 'golden', '*.npz')))
-    return [n for n in all_names if not n.startswith(('amis_', 'choicesampler'))]
+    return [n for n in all_names if not n.startswith(('amis_', 'choicesampler', 'st2profile'))]
 
 
 def load(name):

@@ -187,13 +187,51 @@ _lib.logl_segments_device(model.handle(), model.trajset(traj), 257, 4, d_a.data_
 full = bdist.all_gather_logl(d_out)                       # device tensors through RCCL
 ragged = bdist.all_gather_logl_ragged(d_out, [257])
 host = model.logL_st_batch(ss, thetas, traj)
-sharded = bdist.ShardedModel(model).logL_st_batch(ss, thetas, traj)
+# the product path of a multi-GPU AMIS step: kernel -> device buffer -> all-gather of that buffer -> ONE host copy
+sm = bdist.ShardedModel(model, collective_at_world1=True)
+sharded = sm.logL_st_batch(ss, thetas, traj)
+sharded2 = sm.logL_st_batch(ss[:100], thetas[:100], traj)
+np.random.seed(4)
+sampler = bild_amd.FixedkSampler(traj, sm, k=3, N=64, max_fcomplete=0)
+before = sm.host_copies
+for _ in range(3):
+    sampler.step()
+steps_ok = sm.host_copies - before == 3
+np.random.seed(4)
+plain = bild_amd.FixedkSampler(traj, model, k=3, N=64, max_fcomplete=0)
+for _ in range(3):
+    plain.step()
 dist.barrier()
 ok = (np.array_equal(full.cpu().numpy(), host) and np.array_equal(ragged.cpu().numpy(), host)
-      and np.array_equal(sharded, host) and np.all(np.isfinite(host)))
+      and np.array_equal(sharded, host) and np.array_equal(sharded2, host[:100]) and np.all(np.isfinite(host))
+      and steps_ok and np.array_equal(np.array(sampler.evidences), np.array(plain.evidences)))
 dist.destroy_process_group()
 print("RCCL_OK" if ok else "RCCL_MISMATCH")
 '''
+
+
+def test_sharded_model_pickles_and_copies():
+    """ the wrapper's attribute forwarding must not recurse while an instance is being rebuilt (no GPU needed) """
+    import copy
+    import pickle
+    from bild_amd.dist import ShardedModel
+    from test_core import _SegmentTableModel
+    from amis_cases import _table
+    import bild_amd
+    inner = _SegmentTableModel([_table(7, 2, 40, [11, 29])])
+    sm = ShardedModel(inner)
+    for clone in (copy.deepcopy(sm), pickle.loads(pickle.dumps(sm)), copy.copy(sm)):
+        assert clone.nStates == inner.nStates and clone._group is None
+        assert np.array_equal(clone.transitions, inner.transitions)
+    with pytest.raises(AttributeError):
+        sm.no_such_attribute
+    # a sampler (and its results) holding the wrapper as .model survives the same
+    np.random.seed(1)
+    sampler = bild_amd.FixedkSampler(bild_amd.Trajectory(np.zeros((40, 1))), sm, k=1, N=10, max_fcomplete=0)
+    sampler.step()
+    back = pickle.loads(pickle.dumps(sampler))
+    assert np.array_equal(np.array(back.evidences), np.array(sampler.evidences))
+    assert isinstance(copy.deepcopy(sampler).model, ShardedModel)
 
 
 @pytest.mark.gpu

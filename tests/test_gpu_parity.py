@@ -85,7 +85,8 @@ def test_sampler_batch_vs_oracle(built_lib, path, S, T, k, miss):
     sampler = bild_amd.FixedkSampler(traj, model, k=k, N=n)
     got = sampler.logL(ss, thetas)
     states = H.expand(ss, thetas, T)
-    # the sampler's own st2profile must agree with the batch encoding
+    # (the encoding itself is pinned against the REFERENCE's st2profile output in test_st_seam_against_reference_vectors
+    # below and, without a GPU, in tests/test_profiles.py; this line only ties the sampler method to the batch encoding)
     assert np.array_equal(sampler.st2profile(ss[7], thetas[7])[:], states[7])
     want = oracle.logl_batch(model.arrays(), model.measurement, model.localization_error, traj[:], states)
     assert got.dtype == np.float64 and got.shape == (n,)
@@ -448,8 +449,12 @@ def test_extreme_shapes(built_lib, case):
     pick = rng.choice(n, check, replace=False)
     want = oracle.logl_batch(model.arrays(), model.measurement, model.localization_error, traj[:],
                              H.expand(ss[pick], thetas[pick], T))
-    # the running sums are ~60x longer than in the T = 1000 cases: the tolerance scales with T
-    assert np.max(np.abs(got[pick] - want)) < TOL * max(1, T // 1000), case
+    # north_star quotes |delta| < 1e-8 at T = 1000; the running sums of the T = 60 000 case are 60x longer and the
+    # bar is scaled with T for it (6e-7).  Observed on MI355X (round 2): long_T 2.9e-9 on logL ~ -1.2e6 (relative
+    # 2e-15), many_switches 3e-11, many_tasks 4e-14 -- the unscaled 1e-8 holds for all three with room to spare.
+    worst = np.max(np.abs(got[pick] - want))
+    print(f"extreme shape {case}: max|delta| = {worst:.2e} on |logL| ~ {np.max(np.abs(want)):.1e}")
+    assert worst < TOL * max(1, T // 1000), case
 
 
 def test_model_survives_pickling_and_copying(built_lib):
@@ -584,3 +589,170 @@ def test_torch_after_the_library(built_lib):
               "print('ORDER_OK')\n") % (root, root)
     r = subprocess.run([sys.executable, '-c', script], capture_output=True, text=True, timeout=300)
     assert 'ORDER_OK' in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+
+
+def test_baseline_config4_full_samples_per_trajectory(built_lib):
+    """
+    BASELINE configs[3] at its stated size: 3-state model, T = 2000, 5000 samples PER TRAJECTORY, mixed missing-frame
+    masks (none / iid 10 % / bursty 30 %, frame 0 missing in half of the trajectories) -- six trajectories, 30 000
+    evaluations in one launch per path; 48 spot checks against the oracle plus batch-placement invariance.
+    """
+    import bild_amd
+    from bild_amd.profiles import segments_from_st
+    rng = np.random.default_rng(4404)
+    T, per, k = 2000, 5000, 5
+    model = bild_amd.MultiStateRouse(20, 1, 5, d=3, looppositions=H.LOOPS[3], localization_error=0.1)
+    trajs = []
+    for j, kind in enumerate(['none', 'iid', 'bursty', 'none', 'iid', 'bursty']):
+        miss = H.missing_mask(rng, T, kind)
+        if j % 2 == 1:
+            miss = np.union1d(miss, [0])
+        trajs.append(model.trajectory_from_loopingprofile(H.random_profile(rng, T, 3, 300), missing_frames=miss, rng=rng))
+    ss, thetas = H.candidate_profiles(rng, len(trajs) * per, k, 3)
+    seg_start, seg_state = segments_from_st(ss, thetas, T)
+    tid = np.repeat(np.arange(len(trajs)), per).astype(np.int32)
+    results = {}
+    for path in ('auto', 'dense'):
+        model.path = path
+        got = model.logL_segments(seg_start, seg_state, trajs, tid)
+        assert got.shape == (len(trajs) * per,) and np.all(np.isfinite(got))
+        worst = _spot_check(model, trajs, seg_start, seg_state, tid, got, np.random.default_rng(1), 48, [T] * len(trajs))
+        assert worst < TOL, (path, worst)
+        results[path] = got
+    assert np.max(np.abs(results['auto'] - results['dense'])) < TOL
+    # one trajectory at a time through the sampler seam: same numbers as in the fused batch, bit for bit
+    model.path = 'auto'
+    for j in (1, 5):
+        sl = slice(j * per, (j + 1) * per)
+        sampler = bild_amd.FixedkSampler(trajs[j], model, k=k, N=per, max_fcomplete=0)
+        assert np.array_equal(sampler.logL(ss[sl], thetas[sl]), results['auto'][sl])
+
+
+def test_baseline_config5_full_inference(built_lib):
+    """
+    BASELINE configs[4] on one GPU: the full adaptive-k loop (`sample_many`, default sampler settings: N = 100,
+    init_runs = 20, certainty 0.99) on 64 synthetic trajectories of experimental length, T ~ U{150..600}.
+    Against the oracle: >= 32 likelihoods drawn from the samplers' pools, the likelihood of EVERY best profile, and
+    the boundary polishing (GPU-driven vs oracle-driven) of every result.
+    """
+    import bild_amd
+    from bild_amd import postproc
+    from oracle import oracle
+    rng = np.random.default_rng(64)
+    model = bild_amd.MultiStateRouse(20, 1, 5, d=3, localization_error=0.1)
+    trajs = []
+    for _ in range(64):
+        T = int(rng.integers(150, 601))
+        trajs.append(model.trajectory_from_loopingprofile(H.random_profile(rng, T, 2, 120), rng=rng))
+    np.random.seed(640)
+    results = bild_amd.sample_many(trajs, model, return_exceptions=True)
+    failed = [r for r in results if isinstance(r, Exception)]
+    assert not failed, repr(failed[:1])
+    oracle_model = _OracleRouse(model)
+    n_steps = sum(len(s.samples) for r in results for s in r.samplers)
+    assert n_steps > 64 * 20                                  # at least the initial runs of k = 0 everywhere
+
+    # (i) likelihoods out of the samplers' pools
+    pools = [(r, s, smp) for r in results for s in r.samplers for smp in s.samples if len(smp['logLs'])]
+    worst = 0.0
+    for idx in rng.choice(len(pools), 48, replace=False):
+        r, s, smp = pools[idx]
+        i = int(rng.integers(len(smp['logLs'])))
+        T = len(r.traj)
+        states = H.expand(smp['ss'][i:i + 1], smp['thetas'][i:i + 1], T)[0]
+        want = oracle.logl(model.arrays(), model.measurement, model._get_noise(r.traj), r.traj[:], states)
+        worst = max(worst, abs(smp['logLs'][i] - want))
+    assert worst < TOL, worst
+
+    # (ii) every best profile, (iii) boundary polishing driven by the GPU and by the oracle
+    moved = 0
+    for r in results:
+        prof = r.best_profile()
+        assert abs(model.logL(prof, r.traj) - oracle_model.logL(prof, r.traj)) < TOL
+        try:
+            pg = postproc.optimize_boundary(prof, r.traj, model)
+        except postproc.BoundaryEliminationError:
+            with pytest.raises(postproc.BoundaryEliminationError):
+                postproc.optimize_boundary(prof, r.traj, oracle_model)
+            continue
+        pc = postproc.optimize_boundary(prof, r.traj, oracle_model)
+        assert pg == pc
+        assert model.logL(pg, r.traj) >= model.logL(prof, r.traj) - 1e-9
+        moved += int(np.sum(pg[:] != prof[:]))
+    # the inference finds the switches it should: most trajectories of 150-600 frames with dwell ~120 have some
+    ks = np.array([int(r.best_k()) for r in results])
+    assert np.mean(ks > 0) > 0.5, ks
+
+
+def test_nonsymmetric_propagator_follows_the_textbook_filter(built_lib):
+    """
+    A propagator B that is not symmetric cannot come out of the reference's model classes (rouse builds B = exp(-kA)
+    from a symmetric connectivity matrix); it can only be passed in through `from_arrays`.  On such input the
+    reference's two kernels already disagree with each other -- the Cython kernel reads the lower triangle as if B were
+    symmetric (dsymv, pyx:210-239), the NumPy kernel forms B C B (MSRouse_logL_py.py:109-110) -- and this library
+    follows NEITHER: it runs the Kalman predict  M <- B M + G,  C <- B C B^T + Sig  (dense vector path; the modal
+    path and the matrix-pipe kernel refuse the model).  Stated here so that nobody has to guess.
+    """
+    import bild_amd
+    from bild_amd import _lib
+    from oracle import oracle
+    rng = np.random.default_rng(12)
+    N, d, T = 6, 2, 60
+    a = {k2: v.copy() for k2, v in H.DuckModel(N=N, d=d).arrays().items()}
+    a['B'][0, 0, 1] += 0.02
+    a['B'][1, 3, 2] -= 0.015
+    w, err = H.end2end(N), np.array([0.2, 0.2])
+    model = bild_amd.MultiStateRouse.from_arrays(a['B'], a['G'], a['Sig'], a['M0'], a['C0'], w, localization_error=err)
+    assert model.handle().query(_lib.Q_MODAL_OK) == 0
+    x = rng.standard_normal((T, d))
+    x[7] = np.nan
+    states = H.random_profile(rng, T, 2, 15)
+
+    def textbook(states):
+        M, C = a['M0'][states[0]].copy(), a['C0'][states[0]].copy()
+        tot = 0.0
+        for t in range(T):
+            if t > 0:
+                B, G, Sig = a['B'][states[t]], a['G'][states[t]], a['Sig'][states[t]]
+                M, C = B @ M + G, B @ C @ B.T + Sig
+            if np.any(np.isnan(x[t])):
+                continue
+            Cw = C @ w
+            S = w @ Cw + err[0] ** 2
+            nu = x[t] - w @ M
+            tot += np.sum(-0.5 * (nu ** 2 / S + np.log(S) + np.log(2 * np.pi)))
+            M = M + np.outer(Cw, nu) / S
+            C = C - np.outer(Cw, Cw) / S
+        return tot
+
+    got = model.logL(H.ProfileView(states), x)
+    assert abs(got - textbook(states)) < TOL
+    for flavor in ('numpy', 'cython'):
+        other = oracle.logl(a, w, err, x, states, flavor=flavor)
+        assert abs(got - other) > 1e-6, flavor        # neither reference kernel: see the docstring
+    with pytest.raises(_lib.BildAmdError):
+        model.path = 'modal'
+        model.logL(H.ProfileView(states), x)
+
+
+def test_st_seam_against_reference_vectors(built_lib):
+    """
+    Row a2 on the GPU path: for every batch of tests/golden/st2profile.npz (profiles returned by the REFERENCE's own
+    FixedkSampler.st2profile) the seam `logL_st_batch(ss, thetas)` -- native conversion inside bild_logl_st -- must give
+    exactly what the expanded reference profiles give through `logL_batch`: any disagreement about a switch frame shows.
+    """
+    import bild_amd
+    from test_profiles import _st_golden
+    rng = np.random.default_rng(77)
+    models = {S: bild_amd.MultiStateRouse(20, 1, 5, d=3, looppositions=H.LOOPS[S], localization_error=0.1) for S in (2, 3)}
+    trajs = {}
+    n = 0
+    for ss, thetas, T, S, want_states in _st_golden():
+        model = models[S]
+        if (S, T) not in trajs:
+            trajs[S, T] = model.trajectory_from_loopingprofile(H.random_profile(rng, T, S, max(T // 4, 1)), rng=rng)
+        a = model.logL_st_batch(ss, thetas, trajs[S, T])
+        b = model.logL_batch(want_states, trajs[S, T])
+        assert np.array_equal(a, b), (T, S)
+        n += len(a)
+    assert n > 1000

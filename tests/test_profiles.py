@@ -112,3 +112,53 @@ def test_loopingprofile_reference_fixture():
     assert np.array_equal(state_probabilities(profs), [[0.5, 0, 0.5, 0, 0.5], [0.5, 1, 0.5, 1, 0.5]])
     assert np.array_equal(state_probabilities(profs, nStates=3),
                           [[0.5, 0, 0.5, 0, 0.5], [0.5, 1, 0.5, 1, 0.5], [0, 0, 0, 0, 0]])
+
+
+def _st_golden():
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'st2profile.npz'))
+    for i in range(int(z['n_cases'])):
+        yield (z[f'ss_{i}'], z[f'thetas_{i}'], int(z[f'T_{i}']), int(z[f'S_{i}']), z[f'states_{i}'].astype(np.int64))
+
+
+def test_st_encoding_against_the_reference_vectors(built_lib):
+    """
+    Profiles returned by the REFERENCE's FixedkSampler.st2profile (tests/golden/make_st_golden.py) against
+    (i) the NumPy statement of the encoding, (ii) the native conversion behind bild_logl_st, (iii) this package's
+    st2profile.  Bit-exact integer work.
+    """
+    from bild_amd import _lib
+    n_total = 0
+    for ss, thetas, T, S, want in _st_golden():
+        a, b = segments_from_st(ss, thetas, T)
+        assert np.array_equal(states_from_segments(a, b, T), want)
+        na, nb = _lib.segments_from_st(ss, thetas, T, S)
+        assert np.array_equal(na, a) and np.array_equal(nb, b)
+        sampler = FixedkSampler.__new__(FixedkSampler)
+        sampler.traj = np.zeros((T, 1))
+        for r in range(0, len(ss), 5):
+            assert np.array_equal(sampler.st2profile(ss[r], thetas[r])[:], want[r])
+        n_total += len(ss)
+    assert n_total > 1000
+
+
+def test_native_st_conversion_equals_numpy_on_random_batches(built_lib):
+    """ sequential cumsum, one multiply, floor: the native loop and NumPy agree in every bit, also per-sample T """
+    from bild_amd import _lib
+    rng = np.random.default_rng(5)
+    for k in (0, 1, 4, 20):
+        n = 4000
+        ss = rng.dirichlet(rng.choice([0.05, 1.0, 30.0]) * np.ones(k + 1), size=n)
+        thetas = rng.integers(3, size=(n, k + 1))
+        Ts = rng.integers(1, 3000, size=n).astype(np.int32)
+        na, nb = _lib.segments_from_st(ss, thetas, Ts, 3)
+        for T in np.unique(Ts)[::97]:
+            sel = Ts == T
+            a, b = segments_from_st(ss[sel], thetas[sel], int(T))
+            assert np.array_equal(na[sel], a) and np.array_equal(nb[sel], b)
+    # refused: states out of range, negative or non-finite interval lengths
+    import pytest
+    good_s, good_t = np.array([[0.5, 0.5]]), np.array([[0, 1]])
+    for bad_s, bad_t in ((good_s, np.array([[0, 3]])), (np.array([[np.nan, 0.5]]), good_t), (np.array([[-0.5, 1.5]]), good_t)):
+        with pytest.raises(_lib.BildAmdError):
+            _lib.segments_from_st(bad_s, bad_t, 100, 3)
