@@ -228,14 +228,19 @@ def main():
     d_start = torch.from_numpy(seg_start).to(dev)                        # candidates resident in HBM
     d_state = torch.from_numpy(seg_state).to(dev)
     d_tid = torch.from_numpy(traj_id).to(dev) if traj_id is not None else None
+    # launch order of the resident candidates (a derived descriptor like the segments themselves: computed on the host
+    # from the same (s, theta) batch, resident in HBM before the timed region; the api_seam figure includes computing it)
+    order = _lib.schedule_segments(h, ts, seg_start, traj_id, path=args.path)
+    d_order = torch.from_numpy(order).to(dev)
     pad = max(sizes)
     d_out = torch.zeros(pad, dtype=torch.float64, device=dev)
     d_all = torch.empty(pad * world, dtype=torch.float64, device=dev)
 
-    def step(path):
+    def step(path, prefix=True):
         stream = torch.cuda.current_stream().cuda_stream
         _lib.logl_segments_device(h, ts, n, k + 1, d_start.data_ptr(), d_state.data_ptr(),
-                                  d_tid.data_ptr() if d_tid is not None else 0, d_out.data_ptr(), stream=stream, path=path)
+                                  d_tid.data_ptr() if d_tid is not None else 0, d_out.data_ptr(), stream=stream, path=path,
+                                  d_order=d_order.data_ptr() if prefix else 0, prefix=prefix)
         if world > 1:                                 # the one collective of an AMIS step
             if args.backend == 'nccl':
                 bdist.all_gather_logl(d_out, d_all)
@@ -277,8 +282,9 @@ def main():
     except Exception:
         pass
     can, exe = _lib.flop_count(h, ts, n, traj_id=traj_id, path=args.path)
-    frames_frac = _lib.frames_executed_fraction(h, ts, seg_start, traj_id, path=args.path) if hasattr(_lib, 'frames_executed_fraction') else 1.0
+    frames_frac = _lib.frames_executed_fraction(h, ts, seg_start, traj_id, order, path=args.path)
     exe *= frames_frac
+    prefix_bytes, prefix_ms = _lib.prefix_info(ts)
     ksec = kernel_ms * 1e-3
     is_mfma = 'mfma' in kname
     alg_bytes = n * (k + 1) * 8 + n * 8 + sum(len(t) for t in trajs) * 3 * 8
@@ -292,6 +298,10 @@ def main():
         'flops_basis': 'operations the kernel executes: modal recursion on the reduced chain, frames actually run',
         'flop_per_eval_executed': exe / n,
         'frames_executed_fraction': frames_frac,
+        'prefix_table': {'bytes': prefix_bytes, 'build_ms_once_per_trajectory_set': prefix_ms,
+                         'note': 'filter states before any switch, per (trajectory, state, frame): built once per trajectory '
+                                 'set by the likelihood kernel itself, outside the timed region like the upload of the '
+                                 'trajectory; candidates start at their first switch (bit-identical results)'},
         'kernel_ms': kernel_ms,
         'traffic': traffic,
         'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC passes, gfx950 correction applied; profiles/r02_hbm_traffic.json)',
@@ -342,6 +352,19 @@ def main():
             result['api_seam']['max_abs_diff_vs_device_entry'] = float(np.max(np.abs(got - d_out[:n].cpu().numpy())))
 
     if rank == 0 and world == 1 and args.scaling == 'weak':
+        if not args.no_secondary and prefix_bytes:
+            reps = max(5, args.steps // 3)
+            ndt, nkms, nname = timed(lambda: step(args.path, prefix=False), reps, 1)
+            _, nexe = _lib.flop_count(h, ts, n, traj_id=traj_id, path=args.path)
+            result['without_prefix_table'] = {
+                'what': 'the same batch with every candidate run from frame 0 (BILD_NO_PREFIX, array order)',
+                'value': n * reps / ndt, 'unit': 'evals/s', 'kernel': nname, 'kernel_ms': nkms,
+                'achieved': nexe / (nkms * 1e-3) / 1e12, 'frac': nexe / (nkms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+            }
+            a_out = d_out[:n].cpu().numpy().copy()
+            step(args.path)
+            torch.cuda.synchronize()
+            result['without_prefix_table']['max_abs_diff_vs_default'] = float(np.max(np.abs(a_out - d_out[:n].cpu().numpy())))
         if not args.no_secondary and args.path != 'dense':
             reps = max(3, args.steps // 10)
             ddt, dkms, dname = timed(lambda: step('dense'), reps, 1)

@@ -20,6 +20,7 @@ PATH_AUTO, PATH_DENSE, PATH_MODAL = 0, 1, 2
 PATHS = {'auto': PATH_AUTO, 'dense': PATH_DENSE, 'modal': PATH_MODAL}
 MODEL_NO_REDUCE = 1
 VALIDATE_DEVICE = 0x10
+NO_PREFIX = 0x20
 
 Q_N, Q_D, Q_S, Q_MODAL_OK, Q_NP, Q_NEFF, Q_HAS_G = range(7)
 X_LAMBDA, X_SIGMA, X_Q, X_WQ, X_R, X_C0Q, X_V = range(7)
@@ -56,6 +57,11 @@ _SIGNATURES = {
     'bild_logl_profiles': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int64, _ip, _ip, ctypes.c_uint, _dp]),
     'bild_logl_segments_device': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, _vp, _vp, _vp,
                                                  ctypes.c_uint, _vp, _vp]),
+    'bild_schedule_segments': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, _ip, _ip, ctypes.c_uint, _ip]),
+    'bild_logl_segments_device_ordered': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, _vp, _vp, _vp, _vp,
+                                                         ctypes.c_uint, _vp, _vp]),
+    'bild_frames_executed': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, _ip, _ip, _ip, ctypes.c_uint, _dp, _dp]),
+    'bild_prefix_info': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int64), _dp]),
     'bild_flop_count': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, _ip, ctypes.c_uint, _dp, _dp]),
     'bild_kernel_timing': (ctypes.c_int, [ctypes.c_int]),
     'bild_kernel_timing_read': (ctypes.c_int, [_dp, ctypes.POINTER(ctypes.c_int64), ctypes.c_char_p, ctypes.c_int]),
@@ -209,18 +215,18 @@ class TrajSetHandle:
             self._h = None
 
 
-def logl_segments(model, ts, seg_start, seg_state, traj_id=None, path='auto'):
+def logl_segments(model, ts, seg_start, seg_state, traj_id=None, path='auto', prefix=True):
     seg_start, seg_state = i32(seg_start), i32(seg_state)
     n, K1 = seg_start.shape
     assert seg_state.shape == (n, K1)
     tid = None if traj_id is None else i32(traj_id)
     out = np.empty(n, dtype=np.float64)
     check(lib().bild_logl_segments(model._h, ts._h, n, K1, iptr(seg_start), iptr(seg_state), iptr(tid),
-                                   PATHS[path], dptr(out)))
+                                   _flags(path, prefix=prefix), dptr(out)))
     return out
 
 
-def logl_st(model, ts, ss, thetas, traj_id=None, path='auto'):
+def logl_st(model, ts, ss, thetas, traj_id=None, path='auto', prefix=True):
     """ the sampler's (s, theta) batch as it is: switch frames are computed natively (bild_logl_st) """
     ss = f64(ss)
     thetas = np.ascontiguousarray(thetas, dtype=np.int64)
@@ -230,7 +236,7 @@ def logl_st(model, ts, ss, thetas, traj_id=None, path='auto'):
     assert ss.shape == (n, K1)
     tid = None if traj_id is None else i32(traj_id)
     out = np.empty(n, dtype=np.float64)
-    check(lib().bild_logl_st(model._h, ts._h, n, K1, dptr(ss), thetas.ctypes.data_as(_vp), iptr(tid), PATHS[path], dptr(out)))
+    check(lib().bild_logl_st(model._h, ts._h, n, K1, dptr(ss), thetas.ctypes.data_as(_vp), iptr(tid), _flags(path, prefix=prefix), dptr(out)))
     return out
 
 
@@ -269,10 +275,48 @@ def logl_profiles(model, ts, states, traj_id=None, path='auto'):
     return out
 
 
-def logl_segments_device(model, ts, n, K1, d_seg_start, d_seg_state, d_traj_id, d_out, stream=0, path='auto', validate=False):
-    """ raw device pointers (ints); asynchronous on `stream` (validate=True: descriptors checked on the device first) """
-    check(lib().bild_logl_segments_device(model._h, ts._h, n, K1, _vp(d_seg_start), _vp(d_seg_state),
-                                          _vp(d_traj_id) if d_traj_id else None, PATHS[path] | (VALIDATE_DEVICE if validate else 0),
+def _flags(path, validate=False, prefix=True):
+    return PATHS[path] | (VALIDATE_DEVICE if validate else 0) | (0 if prefix else NO_PREFIX)
+
+
+def schedule_segments(model, ts, seg_start, traj_id=None, path='auto', prefix=True):
+    """ launch order for device-resident candidates (bild_schedule_segments): (n,) int32, order[slot] = sample """
+    seg_start = i32(seg_start)
+    n, K1 = seg_start.shape
+    tid = None if traj_id is None else i32(traj_id)
+    order = np.empty(n, dtype=np.int32)
+    check(lib().bild_schedule_segments(model._h, ts._h, n, K1, iptr(seg_start), iptr(tid), _flags(path, prefix=prefix), iptr(order)))
+    return order
+
+
+def frames_executed_fraction(model, ts, seg_start, traj_id=None, order=None, path='auto', prefix=True):
+    """ share of the (task, frame) pairs of a batch that the launch runs itself (the rest comes out of the prefix table) """
+    seg_start = i32(seg_start)
+    n, K1 = seg_start.shape
+    tid = None if traj_id is None else i32(traj_id)
+    od = None if order is None else i32(order)
+    tot, run = ctypes.c_double(0), ctypes.c_double(0)
+    check(lib().bild_frames_executed(model._h, ts._h, n, K1, iptr(seg_start), iptr(tid), iptr(od), _flags(path, prefix=prefix),
+                                     ctypes.byref(tot), ctypes.byref(run)))
+    return run.value / tot.value if tot.value else 1.0
+
+
+def prefix_info(ts):
+    """ (bytes, build_ms) of the trajectory set's prefix table; (0, 0.0) when none has been built """
+    b, ms = ctypes.c_int64(0), ctypes.c_double(0)
+    check(lib().bild_prefix_info(ts._h, ctypes.byref(b), ctypes.byref(ms)))
+    return b.value, ms.value
+
+
+def logl_segments_device(model, ts, n, K1, d_seg_start, d_seg_state, d_traj_id, d_out, stream=0, path='auto', validate=False,
+                         d_order=0, prefix=True):
+    """
+    raw device pointers (ints); asynchronous on `stream` (validate=True: descriptors checked on the device first);
+    d_order: device pointer of the launch order from `schedule_segments`, 0 = the order of the arrays
+    """
+    check(lib().bild_logl_segments_device_ordered(model._h, ts._h, n, K1, _vp(d_seg_start), _vp(d_seg_state),
+                                          _vp(d_traj_id) if d_traj_id else None, _vp(d_order) if d_order else None,
+                                          _flags(path, validate, prefix),
                                           _vp(stream) if stream else None, _vp(d_out)))
 
 

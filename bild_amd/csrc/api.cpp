@@ -7,7 +7,10 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
+#include <atomic>
 #include <mutex>
+#include <queue>
 #include <new>
 #include <string>
 #include <utility>
@@ -170,6 +173,13 @@ struct bild_trajset {
     double *d_x = nullptr; // all trajectories, each followed by one padding row, then kZeroPad zeros
     double *d_zeros = nullptr;
     TrajDesc *d_descs = nullptr;
+    // prefix table of the vector kernels' modal path (common.h: prefix_record_doubles), built at the first evaluation
+    // that can use it: 0 not tried yet, 1 built, -1 not available for this set (too large, or the build failed)
+    mutable std::mutex prefix_mu;
+    mutable std::atomic<int> prefix_state{0};
+    mutable double *d_prefix = nullptr;
+    mutable int64_t prefix_records = 0;
+    mutable double prefix_build_ms = 0.0;
 };
 constexpr int kZeroPad = 8;
 
@@ -519,8 +529,95 @@ int pick_mode(const bild_model &m, unsigned flags, int *mode)
     }
 }
 
+int fill_params(const bild_model &m, const bild_trajset &ts, int mode, KParams &p)
+{
+    p.states = m.d_states[mode];
+    p.tab = m.d_tab[mode];
+    p.tab_doubles = (int32_t)m.blob_tab[mode].size();
+    p.S = m.S;
+    p.d = m.d;
+    p.has_G = m.has_G ? 1 : 0;
+    p.all_valid = ts.all_valid ? 1 : 0;
+    p.trajs = ts.d_descs;
+    p.dstar_max = ts.dstar_max;
+    p.zeros = ts.d_zeros;
+    return BILD_OK;
+}
+
+// The prefix table of a trajectory set (common.h), built once: the likelihood kernel itself runs one task per
+// (trajectory, covariance chain, initial state) with a profile that never switches and stores its state after every
+// frame.  Synchronous (the one-time cost of a set, like its upload); afterwards any stream may read the table.
+int ensure_prefix(const bild_model &m, const bild_trajset &ts, hipStream_t st)
+{
+    std::lock_guard<std::mutex> lk(ts.prefix_mu);
+    if (ts.prefix_state != 0) return BILD_OK;
+    ts.prefix_state = -1;
+    if (getenv("BILD_NO_PREFIX")) return BILD_OK;
+    const int NP = m.NPm[kModal];
+    Geometry geom{};
+    if (!builder_geometry(NP, &geom)) return BILD_OK;
+    const size_t lds = lds_bytes(m, geom, kModal);
+    if (lds > 160 * 1024) return BILD_OK;
+    const size_t bytes = (size_t)ts.prefix_records * prefix_record_doubles(NP) * sizeof(double);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return BILD_OK;
+    if (bytes > free_b / 4 || bytes > ((size_t)16 << 30)) return BILD_OK; // the table is an optimisation, not a requirement
+    const int S = m.S;
+    const int64_t nb = (int64_t)ts.n_traj * S;
+    std::vector<int32_t> host((size_t)3 * nb);
+    for (int j = 0; j < ts.n_traj; ++j)
+        for (int s = 0; s < S; ++s) {
+            host[(size_t)j * S + s] = 0;                 // seg_start
+            host[(size_t)nb + (size_t)j * S + s] = s;    // seg_state
+            host[(size_t)2 * nb + (size_t)j * S + s] = j; // traj_id
+        }
+    int32_t *d_desc = nullptr;
+    double *d_tab = nullptr, *d_sink = nullptr;
+    auto cleanup = [&](bool keep) {
+        if (d_desc) (void)hipFree(d_desc);
+        if (d_sink) (void)hipFree(d_sink);
+        if (!keep && d_tab) (void)hipFree(d_tab);
+    };
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool ok = hipMalloc((void **)&d_desc, host.size() * sizeof(int32_t)) == hipSuccess &&
+              hipMalloc((void **)&d_sink, (size_t)nb * ts.dstar_max * sizeof(double)) == hipSuccess &&
+              hipMalloc((void **)&d_tab, bytes) == hipSuccess &&
+              hipMemcpy(d_desc, host.data(), host.size() * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess &&
+              hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+    if (ok) {
+        KParams p{};
+        fill_params(m, ts, kModal, p);
+        p.ntasks = nb * ts.dstar_max;
+        p.K1 = 1;
+        p.seg_start = d_desc;
+        p.seg_state = d_desc + nb;
+        p.traj_id = d_desc + 2 * nb;
+        p.out = d_sink;
+        p.prefix_dump = d_tab;
+        const int64_t tpb = (int64_t)geom.W * geom.tasks_per_wave();
+        const int grid = (int)std::min<int64_t>(std::max<int64_t>((p.ntasks + tpb - 1) / tpb, 1), 256 * 16);
+        (void)hipEventRecord(e0, st);
+        ok = launch_logl(geom, kModal, p, grid, lds, (void *)st) == 0;
+        (void)hipEventRecord(e1, st);
+        ok = ok && hipStreamSynchronize(st) == hipSuccess;
+        float ms = 0.f;
+        if (ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) ts.prefix_build_ms = ms;
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    cleanup(ok);
+    if (ok) {
+        ts.d_prefix = d_tab;
+        ts.prefix_state = 1;
+    } else {
+        (void)hipGetLastError();
+    }
+    return BILD_OK;
+}
+
 int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1, const int32_t *d_seg_start,
-                 const int32_t *d_seg_state, const int32_t *d_traj_id, unsigned flags, hipStream_t st, double *d_out)
+                 const int32_t *d_seg_state, const int32_t *d_traj_id, const int32_t *d_order, unsigned flags,
+                 hipStream_t st, double *d_out)
 {
     int mode;
     int rc = pick_mode(m, flags, &mode);
@@ -552,21 +649,19 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
     }
 
     KParams p{};
-    p.states = m.d_states[mode];
-    p.tab = m.d_tab[mode];
-    p.tab_doubles = (int32_t)m.blob_tab[mode].size();
-    p.S = m.S;
-    p.d = m.d;
-    p.has_G = m.has_G ? 1 : 0;
-    p.all_valid = ts.all_valid ? 1 : 0;
-    p.trajs = ts.d_descs;
-    p.dstar_max = ts.dstar_max;
+    fill_params(m, ts, mode, p);
     p.ntasks = n * ts.dstar_max;
     p.K1 = K1;
     p.seg_start = d_seg_start;
     p.seg_state = d_seg_state;
     p.traj_id = d_traj_id;
-    p.zeros = ts.d_zeros;
+    if (fam == kVector) {
+        p.order = d_order;
+        if (mode == kModal && K1 > 0 && !(flags & BILD_NO_PREFIX)) {
+            if (ts.prefix_state == 0) ensure_prefix(m, ts, st);
+            if (ts.prefix_state == 1) p.prefix = ts.d_prefix;
+        }
+    }
     // d* > 1: one partial result per (sample, covariance chain), summed by a second kernel.  The buffer belongs to
     // THIS call (stream-ordered allocation, released behind the reduction): launches of one model on different
     // streams, or a host-buffer call beside a device-buffer call, share nothing.
@@ -614,6 +709,77 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
     return BILD_OK;
 }
 
+// Launch order of a batch (vector kernels, modal path, prefix table in use).  A candidate starts at its first switch, so
+// candidates differ in length; the four (or so) tasks of a wavefront run in lockstep and finish with the longest.
+//  1. sort by remaining length, longest first: a wave's tasks then have neighbouring first switches (little is lost to
+//     the wave-wide start, their basis changes tend to coincide) and long work is dispatched first;
+//  2. when the whole grid is resident at once -- at most OCC workgroups per CU -- nothing is ever re-balanced at run time:
+//     the dispatcher deals workgroups to the 256 CUs round-robin (workgroups b, b + 256, b + 512 share a CU;
+//     measured: profiles/r02_placement.txt), so the sorted workgroups are dealt to CUs longest-processing-time-first
+//     with the CU's number of workgroups as capacity, and written out in that dealing order.
+// Purely a matter of speed: results do not depend on the order, and nothing relies on the dispatcher behaving so.
+// order[slot] = sample.  Returns false when the identity is as good (nothing written).
+bool schedule(const bild_model &m, const bild_trajset &ts, int64_t n, int K1, const int32_t *seg_start, const int32_t *traj_id,
+              unsigned flags, int32_t *order)
+{
+    int mode;
+    if (n < 2 || K1 < 2 || n > INT_MAX || pick_mode(m, flags, &mode) || mode != kModal || m.wide || m.mid) return false;
+    if ((flags & BILD_NO_PREFIX) || ts.prefix_state < 0 || getenv("BILD_NO_PREFIX") || getenv("BILD_NO_SCHEDULE")) return false;
+    Geometry geom{};
+    if (!geometry_for(m.NPm[mode], mode, n * ts.dstar_max, ts.means_max, &geom)) return false;
+    const int Tmax = ts.Tmax;
+    // counting sort by remaining length, descending
+    std::vector<int32_t> count((size_t)Tmax + 2, 0), rem((size_t)n);
+    for (int64_t r = 0; r < n; ++r) {
+        const int T = ts.descs[traj_id ? traj_id[r] : 0].T;
+        int t0 = seg_start[r * K1 + 1];
+        t0 = t0 < 1 ? 1 : (t0 > T ? T : t0);
+        rem[r] = T - t0;
+        ++count[Tmax - rem[r] + 1];
+    }
+    for (int i = 1; i <= Tmax + 1; ++i) count[i] += count[i - 1];
+    std::vector<int32_t> sorted((size_t)n);
+    for (int64_t r = 0; r < n; ++r) sorted[count[Tmax - rem[r]]++] = (int32_t)r;
+    const int64_t per_block = std::max<int64_t>(1, (int64_t)geom.W * geom.tasks_per_wave() / ts.dstar_max);
+    const int64_t nb = (n + per_block - 1) / per_block;
+    const int kCUs = 256;
+    if (nb <= kCUs || nb > (int64_t)kCUs * geom.OCC || (int64_t)geom.W * geom.tasks_per_wave() % ts.dstar_max != 0) {
+        std::copy(sorted.begin(), sorted.end(), order);
+        return true;
+    }
+    // blocks of the sorted list, longest first; block length = its first (longest) sample
+    const int rounds = (int)((nb + kCUs - 1) / kCUs);
+    const int extra = (int)(nb - (int64_t)(rounds - 1) * kCUs); // CUs 0 .. extra-1 take `rounds` workgroups, the others one less
+    typedef std::pair<int64_t, int> Load; // (work so far, CU)
+    std::priority_queue<Load, std::vector<Load>, std::greater<Load>> heap;
+    for (int c = 0; c < kCUs; ++c) heap.push(Load(0, c));
+    std::vector<int> filled(kCUs, 0);
+    std::vector<int64_t> at((size_t)nb, -1); // launch position -> block of the sorted list
+    for (int64_t b = 0; b < nb; ++b) {
+        const Load top = heap.top();
+        heap.pop();
+        const int c = top.second;
+        at[(size_t)c + (size_t)kCUs * filled[c]] = b;
+        ++filled[c];
+        const int cap = c < extra ? rounds : rounds - 1;
+        if (filled[c] < cap) heap.push(Load(top.first + rem[sorted[b * per_block]] + 1, c));
+    }
+    // only the last block of the sorted list can be short: it goes to the last position, so that blocks of samples and
+    // workgroups stay aligned
+    for (int64_t pos = 0; pos < nb; ++pos)
+        if (at[(size_t)pos] == nb - 1) {
+            std::swap(at[(size_t)pos], at[(size_t)nb - 1]);
+            break;
+        }
+    int64_t w = 0;
+    for (int64_t pos = 0; pos < nb; ++pos) {
+        const int64_t b = at[(size_t)pos];
+        const int64_t lo = b * per_block, hi = std::min(n, lo + per_block);
+        for (int64_t i = lo; i < hi; ++i) order[w++] = sorted[i];
+    }
+    return true;
+}
+
 // Host buffers in, host buffer out.  `fill(h_start, h_state)` writes the n x K1 run-length segments straight into
 // pinned staging memory (and validates them: these indices drive device addressing); then ONE host-to-device copy of
 // the packed block [seg_start | seg_state | traj_id], the launch, one device-to-host copy of the results, one
@@ -629,23 +795,27 @@ int run_staged(const bild_model *m, const bild_trajset *ts, int64_t n, int K1, c
                 return fail(BILD_ERR_INVALID, "traj_id[%lld]=%d out of range", (long long)r, traj_id[r]);
     std::lock_guard<std::mutex> call_lock(m->call_mu);
     const size_t nseg = (size_t)n * K1;
-    const size_t in_bytes = (2 * nseg + (traj_id ? (size_t)n : 0)) * sizeof(int32_t);
+    const size_t in_cap = (2 * nseg + 2 * (size_t)n) * sizeof(int32_t); // room for traj_id and the launch order
     // a previous call that left its results on the device may still be reading the staging block
     if (m->h_in_busy) HIP_TRY(hipEventSynchronize(m->h_in_event));
     m->h_in_busy = false;
     {
         std::lock_guard<std::mutex> lk(m->mu);
-        if ((rc = m->h_in.reserve(in_bytes))) return rc;
-        if ((rc = m->ws_in.reserve(in_bytes))) return rc;
+        if ((rc = m->h_in.reserve(in_cap))) return rc;
+        if ((rc = m->ws_in.reserve(in_cap))) return rc;
         if (!d_out_user) {
             if ((rc = m->h_out.reserve((size_t)n * sizeof(double)))) return rc;
             if ((rc = m->ws_out.reserve((size_t)n * sizeof(double)))) return rc;
         }
     }
     int32_t *h_start = (int32_t *)m->h_in.ptr, *h_state = h_start + nseg, *h_tid = h_state + nseg;
+    int32_t *h_order = h_tid + (traj_id ? n : 0);
     if ((rc = fill(h_start, h_state))) return rc;
     if (traj_id) std::memcpy(h_tid, traj_id, (size_t)n * sizeof(int32_t));
+    const bool ordered = schedule(*m, *ts, n, K1, h_start, traj_id, flags, h_order);
+    const size_t in_bytes = (2 * nseg + (traj_id ? (size_t)n : 0) + (ordered ? (size_t)n : 0)) * sizeof(int32_t);
     int32_t *d_start = (int32_t *)m->ws_in.ptr, *d_state = d_start + nseg, *d_tid = traj_id ? d_state + nseg : nullptr;
+    const int32_t *d_order = ordered ? d_state + nseg + (traj_id ? n : 0) : nullptr;
     double *d_out = d_out_user ? d_out_user : (double *)m->ws_out.ptr;
     hipStream_t st = d_out_user ? st_user : m->stream;
     HIP_TRY(hipMemcpyAsync(d_start, h_start, in_bytes, hipMemcpyHostToDevice, st));
@@ -653,7 +823,7 @@ int run_staged(const bild_model *m, const bild_trajset *ts, int64_t n, int K1, c
         HIP_TRY(hipEventRecord(m->h_in_event, st));
         m->h_in_busy = true;
     }
-    rc = launch_batch(*m, *ts, n, K1, d_start, d_state, d_tid, flags, st, d_out);
+    rc = launch_batch(*m, *ts, n, K1, d_start, d_state, d_tid, d_order, flags, st, d_out);
     if (rc) {
         (void)hipStreamSynchronize(st);
         return rc;
@@ -858,6 +1028,14 @@ int bild_trajset_create(const bild_model *m, int n_traj, const int32_t *T, const
         ts->Tmax = std::max(ts->Tmax, (int)T[j]);
         off += T[j];
     }
+    {
+        int64_t rec = 0;
+        for (int j = 0; j < n_traj; ++j) {
+            ts->descs[j].prefix_rec0 = rec;
+            rec += (int64_t)T[j] * m->S * ts->dstar_max;
+        }
+        ts->prefix_records = rec;
+    }
     he = hipMemcpy(ts->d_x, xd.data(), xd.size() * sizeof(double), hipMemcpyHostToDevice);
     if (he != hipSuccess) return cleanup(fail(BILD_ERR_HIP, "hipMemcpy failed: %s", hipGetErrorString(he)));
     he = hipMalloc((void **)&ts->d_descs, (size_t)n_traj * sizeof(TrajDesc));
@@ -873,6 +1051,7 @@ int bild_trajset_destroy(bild_trajset *ts)
     if (!ts) return BILD_OK;
     if (ts->d_x) (void)hipFree(ts->d_x);
     if (ts->d_descs) (void)hipFree(ts->d_descs);
+    if (ts->d_prefix) (void)hipFree(ts->d_prefix);
     delete ts;
     return BILD_OK;
 }
@@ -889,9 +1068,9 @@ static int check_eval_args(const bild_model *m, const bild_trajset *ts, int64_t 
     return BILD_OK;
 }
 
-int bild_logl_segments_device(const bild_model *m, const bild_trajset *ts, int64_t n, int K1, const int32_t *d_seg_start,
-                              const int32_t *d_seg_state, const int32_t *d_traj_id, unsigned flags, void *hip_stream,
-                              double *d_out)
+int bild_logl_segments_device_ordered(const bild_model *m, const bild_trajset *ts, int64_t n, int K1,
+                                      const int32_t *d_seg_start, const int32_t *d_seg_state, const int32_t *d_traj_id,
+                                      const int32_t *d_order, unsigned flags, void *hip_stream, double *d_out)
 {
     int rc = check_eval_args(m, ts, n, K1);
     if (rc) return rc;
@@ -902,19 +1081,90 @@ int bild_logl_segments_device(const bild_model *m, const bild_trajset *ts, int64
         // checked on the device, verdict read back BEFORE anything is launched: this variant of the call waits
         int *d_err = nullptr;
         int h_err[2] = {0, 0};
-        HIP_TRY(hipMallocAsync((void **)&d_err, 2 * sizeof(int), st));
-        HIP_TRY(hipMemsetAsync(d_err, 0, 2 * sizeof(int), st));
-        int lrc = launch_validate(d_seg_start, d_seg_state, d_traj_id, n, K1, m->S, ts->n_traj, d_err, (void *)st);
+        const size_t err_bytes = (2 + (d_order ? (size_t)n : 0)) * sizeof(int);
+        HIP_TRY(hipMallocAsync((void **)&d_err, err_bytes, st));
+        HIP_TRY(hipMemsetAsync(d_err, 0, err_bytes, st));
+        int lrc = launch_validate(d_seg_start, d_seg_state, d_traj_id, d_order, n, K1, m->S, ts->n_traj, d_err, (void *)st);
         hipError_t ce = lrc == 0 ? hipMemcpyAsync(h_err, d_err, sizeof h_err, hipMemcpyDeviceToHost, st) : (hipError_t)lrc;
         (void)hipFreeAsync(d_err, st);
         if (ce != hipSuccess) return fail(BILD_ERR_HIP, "descriptor check failed to run: %s", hipGetErrorString(ce));
         HIP_TRY(hipStreamSynchronize(st));
         static const char *const what[] = {"", "traj_id out of range", "first segment does not start at frame 0",
-                                           "segment starts are decreasing", "state out of range"};
+                                           "segment starts are decreasing", "state out of range",
+                                           "launch order is not a permutation of the samples"};
         if (h_err[0] != 0)
             return fail(BILD_ERR_INVALID, "device descriptors rejected: %s (e.g. sample %d)", what[h_err[0] & 7], h_err[1]);
     }
-    return launch_batch(*m, *ts, n, K1, d_seg_start, d_seg_state, d_traj_id, flags, st, d_out);
+    return launch_batch(*m, *ts, n, K1, d_seg_start, d_seg_state, d_traj_id, d_order, flags, st, d_out);
+}
+
+int bild_logl_segments_device(const bild_model *m, const bild_trajset *ts, int64_t n, int K1, const int32_t *d_seg_start,
+                              const int32_t *d_seg_state, const int32_t *d_traj_id, unsigned flags, void *hip_stream,
+                              double *d_out)
+{
+    return bild_logl_segments_device_ordered(m, ts, n, K1, d_seg_start, d_seg_state, d_traj_id, nullptr, flags, hip_stream, d_out);
+}
+
+int bild_schedule_segments(const bild_model *m, const bild_trajset *ts, int64_t n, int K1, const int32_t *seg_start,
+                           const int32_t *traj_id, unsigned flags, int32_t *order)
+{
+    if (!m || !ts || !order) return fail(BILD_ERR_INVALID, "NULL argument");
+    if (ts->model != m) return fail(BILD_ERR_INVALID, "trajectory set belongs to a different model");
+    if (n < 0 || K1 < 1) return fail(BILD_ERR_INVALID, "bad sizes");
+    if (n > 0 && !seg_start) return fail(BILD_ERR_INVALID, "NULL buffer");
+    if (traj_id)
+        for (int64_t r = 0; r < n; ++r)
+            if (traj_id[r] < 0 || traj_id[r] >= ts->n_traj) return fail(BILD_ERR_INVALID, "traj_id out of range");
+    if (!schedule(*m, *ts, n, K1, seg_start, traj_id, flags, order))
+        for (int64_t r = 0; r < n; ++r) order[r] = (int32_t)r;
+    return BILD_OK;
+}
+
+int bild_frames_executed(const bild_model *m, const bild_trajset *ts, int64_t n, int K1, const int32_t *seg_start,
+                         const int32_t *traj_id, const int32_t *order, unsigned flags, double *frames_total, double *frames_run)
+{
+    if (!m || !ts || !frames_total || !frames_run || (n > 0 && !seg_start)) return fail(BILD_ERR_INVALID, "NULL argument");
+    int mode;
+    int rc = pick_mode(*m, flags, &mode);
+    if (rc) return rc;
+    const bool prefix = ts->prefix_state == 1 && mode == kModal && !m->wide && !m->mid && !(flags & BILD_NO_PREFIX);
+    Geometry geom{};
+    int tpw = 1;
+    if (prefix && geometry_for(m->NPm[mode], mode, n * ts->dstar_max, ts->means_max, &geom)) tpw = geom.tasks_per_wave();
+    double total = 0.0, run = 0.0;
+    const int ds = ts->dstar_max;
+    // tasks are (slot, chain) pairs, tpw consecutive tasks share a wave and start at the earliest first switch among them
+    const int64_t ntasks = n * ds;
+    for (int64_t w0 = 0; w0 < ntasks; w0 += tpw) {
+        int tw = INT_MAX;
+        for (int64_t t = w0; t < std::min(ntasks, w0 + tpw); ++t) {
+            const int64_t r = order ? order[t / ds] : t / ds;
+            const TrajDesc &td = ts->descs[traj_id ? traj_id[r] : 0];
+            if ((int)(t % ds) >= td.dstar) continue;
+            int t0 = K1 > 1 ? seg_start[r * K1 + 1] : td.T;
+            t0 = t0 < 1 ? 1 : (t0 > td.T ? td.T : t0);
+            tw = std::min(tw, t0);
+        }
+        for (int64_t t = w0; t < std::min(ntasks, w0 + tpw); ++t) {
+            const int64_t r = order ? order[t / ds] : t / ds;
+            const TrajDesc &td = ts->descs[traj_id ? traj_id[r] : 0];
+            if ((int)(t % ds) >= td.dstar) continue;
+            total += td.T;
+            run += prefix ? td.T - tw : td.T;
+        }
+    }
+    *frames_total = total;
+    *frames_run = run;
+    return BILD_OK;
+}
+
+int bild_prefix_info(const bild_trajset *ts, int64_t *bytes, double *build_ms)
+{
+    if (!ts) return fail(BILD_ERR_INVALID, "NULL handle");
+    const bool built = ts->prefix_state == 1;
+    if (bytes) *bytes = built ? ts->prefix_records * prefix_record_doubles(ts->model->NPm[kModal]) * (int64_t)sizeof(double) : 0;
+    if (build_ms) *build_ms = built ? ts->prefix_build_ms : 0.0;
+    return BILD_OK;
 }
 
 int bild_logl_segments(const bild_model *m, const bild_trajset *ts, int64_t n, int K1, const int32_t *seg_start,
@@ -931,7 +1181,8 @@ int bild_logl_segments(const bild_model *m, const bild_trajset *ts, int64_t n, i
             if (a[0] != 0) return fail(BILD_ERR_INVALID, "seg_start[%lld][0] must be 0", (long long)r);
             for (int i = 0; i < K1; ++i) {
                 if (b[i] < 0 || b[i] >= S) return fail(BILD_ERR_INVALID, "state %d out of range at sample %lld", b[i], (long long)r);
-                if (i > 0 && a[i] < a[i - 1]) return fail(BILD_ERR_INVALID, "segment starts of sample %lld are decreasing", (long long)r);
+                if (i > 0 && (a[i] < a[i - 1] || a[i] < 1))
+                    return fail(BILD_ERR_INVALID, "segment starts of sample %lld are decreasing (or a later segment starts at frame 0)", (long long)r);
                 h_start[r * K1 + i] = a[i];
                 h_state[r * K1 + i] = b[i];
             }

@@ -41,7 +41,17 @@ struct TrajDesc {
     int32_t dims[kDMax][kDMax];
     int32_t nvalid;          // frames with data
     int32_t pad_;
+    int64_t prefix_rec0;     // first record of this trajectory in the prefix table (records, see prefix_record_doubles)
 };
+
+// Prefix table (vector kernels, modal path): the filter state after frame t of a task that has not switched yet
+// depends only on (trajectory, covariance chain e, initial state s, t) -- not on the candidate profile.  It is
+// computed once per trajectory set by the likelihood kernel itself (one task per (trajectory, e, s) that stores its
+// state after every frame) and every candidate starts from the record in front of its first switch.
+// Record of frame t, in doubles: NP + kDMax columns of NP rows ([C | M] in the modal basis of s, column layout of
+// the kernels), then sum e^2/S per mean column (kDMax), P, E (mantissa / exponent of the running product of S), pad.
+// Records of trajectory j: prefix_rec0 + ((e * S + s) * T + t).
+constexpr int prefix_record_doubles(int NP) { return (NP + kDMax) * NP + kDMax + 2 + 3; }
 
 struct KParams {
     const double *states; // S state blocks
@@ -58,6 +68,10 @@ struct KParams {
     const int32_t *traj_id; // may be null
     const double *zeros;    // a few zero doubles (stride-0 source for non-mean columns)
     double *out;            // ntasks partial results
+    // vector kernels only (kernels.hip); the others ignore them
+    const int32_t *order;   // slot -> sample (launch order chosen by the host scheduler), null: identity
+    const double *prefix;   // prefix table to start from, null: every task starts at frame 0
+    double *prefix_dump;    // non-null: this launch BUILDS the table (one task per (trajectory, e, s), K1 = 1)
 };
 
 // launch geometry for a padded chain length
@@ -79,8 +93,9 @@ constexpr int group_image_doubles(int NP) { return (NP + kDMax) * NP; }
 // host-callable launchers implemented in kernels.hip
 int launch_logl(const Geometry &g, int mode, const KParams &p, int grid, size_t lds_bytes, void *stream);
 int launch_reduce_partials(const double *partial, double *out, int64_t n, int dstar_max, void *stream);
-int launch_validate(const int32_t *seg_start, const int32_t *seg_state, const int32_t *traj_id, int64_t n, int K1, int S,
-                    int n_traj, int *d_err, void *stream);
+// d_err: 2 ints (verdict, a sample that shows it) followed, when `order` is given, by n hit counters; zeroed by the caller
+int launch_validate(const int32_t *seg_start, const int32_t *seg_state, const int32_t *traj_id, const int32_t *order, int64_t n,
+                    int K1, int S, int n_traj, int *d_err, void *stream);
 // smallest compiled row count >= n_rows, or 0
 int padded_rows(int n_rows);
 // launch geometry for `ntasks` recursions of a chain padded to NP rows, each with up to `means` mean vectors
@@ -88,6 +103,8 @@ int padded_rows(int n_rows);
 // task when fewer mean vectors are needed); env BILD_GEOM=<id> overrides.
 bool geometry_for(int NP, int mode, int64_t ntasks, int means, Geometry *g);
 const char *kernel_name(const Geometry &g, int mode);
+// the geometry whose kernel is also compiled as the builder of the prefix table (KParams::prefix_dump)
+bool builder_geometry(int NP, Geometry *g);
 // dense recursion on the fp64 matrix pipe (dense_mfma.hip): NP a multiple of 4, <= 24
 bool dense_mfma_supported(int NP);
 int launch_logl_dense_mfma(int NP, const KParams &p, void *stream);

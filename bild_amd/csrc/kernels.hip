@@ -166,7 +166,8 @@ __device__ __forceinline__ void matvec_to_lds(XPtr X, const Cols<NP, CPL> &in, d
 //   0: external force (G != 0) and missing frames   1: missing frames   2: neither (every frame valid)
 // LAY: 0 packed groups of G consecutive lanes; 1 a group is a 16-lane block of the f64 4x4x4 matrix instruction
 // (S as a block sum on the matrix pipe); 2 a group is a 16-lane row, cross-lane operands by DPP row broadcast
-template <int NP, int CPL, int G, int W, int OCC, int LAY, int MODE, int FLAVOR>
+// DUMP: this instantiation builds the prefix table (one per chain length is compiled, see launch_geom)
+template <int NP, int CPL, int G, int W, int OCC, int LAY, int MODE, int FLAVOR, bool DUMP = false>
 __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
 {
     constexpr bool HASG = FLAVOR == 0;
@@ -221,12 +222,14 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
     const int64_t gstride = (int64_t)gridDim.x * (kWaves * GPW);
 
     for (int64_t task = ((int64_t)blockIdx.x * kWaves + wv) * GPW + grp; task < p.ntasks; task += gstride) {
-        const int64_t r = task / p.dstar_max;
-        const int e = (int)(task - r * p.dstar_max);
+        const int64_t slot = task / p.dstar_max;
+        const int e = (int)(task - slot * p.dstar_max);
+        const int64_t r = p.order ? p.order[slot] : slot; // launch order is a scheduling matter only
+        const int64_t otask = r * p.dstar_max + e;
         const int tj = p.traj_id ? p.traj_id[r] : 0;
         const TrajDesc *__restrict__ td = p.trajs + tj;
         if (e >= td->dstar) {
-            if (gl == 0) p.out[task] = 0.0;
+            if (gl == 0) p.out[otask] = 0.0;
             continue;
         }
         const int T = td->T;
@@ -494,18 +497,92 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
             if (ALLVALID || !isnan(probe)) update(xv);
         };
 
-        // ---- frame 0: update on the steady state, no predict (pyx:186-190); frames are
-        // fetched one ahead of their use ----------------------------------------------------
+        // ---- where to start.  Without a prefix table: frame 0, an update on the steady state without a predict
+        // (pyx:186-190).  With one: every task of this WAVE starts from the record in front of the earliest first switch
+        // among them (the host scheduler puts tasks with neighbouring first switches into one wave; a task whose own
+        // first switch comes later runs the few frames in between itself, in its initial state -- same arithmetic as
+        // the table's, so the result does not depend on where a task picks up).  Frames are fetched one ahead of
+        // their use. ------------------------------------------------------------------------------------------
+        constexpr int NC = NP + kDMax;
+        constexpr int REC = prefix_record_doubles(NP);
+        int t_begin = 1;
+        const bool restore = !DUMP && p.prefix != nullptr;
+        if (restore) {
+            // first frame this task may not take from the table; >= 1 (an empty first segment starts the table at frame 0)
+            const int mine = next_start < 1 ? 1 : (next_start < T ? next_start : T);
+            int tw = mine;
+            // minimum over the groups of this wave that have a task and a covariance chain to run
+            const int64_t wave_task0 = task - grp;
+#pragma unroll
+            for (int g2 = 0; g2 < GPW; ++g2) {
+                const int src_lane = BLK ? (g2 << 2) : g2 * G;
+                const int other = __builtin_amdgcn_readlane(mine, src_lane);
+                const int64_t t2 = wave_task0 + g2;
+                bool live = t2 < p.ntasks;
+                if (live) {
+                    const int64_t slot2 = t2 / p.dstar_max;
+                    const int64_t r2 = p.order ? p.order[slot2] : slot2;
+                    live = (int)(t2 - slot2 * p.dstar_max) < p.trajs[p.traj_id ? p.traj_id[r2] : 0].dstar;
+                }
+                if (live && other < tw) tw = other;
+            }
+            t_begin = __builtin_amdgcn_readfirstlane(tw); // the same in every lane that is still here
+        }
         double xc[CPL], xn[CPL], pc, pn;
-        fetch(xc, pc); // frame 0
-        fetch(xn, pn); // frame 1 (or the padding row)
-        if (ALLVALID || !isnan(pc)) update(xc);
-        for (int t = 1; t < T; ++t) {
+        if (restore) {
+            const double *__restrict__ rec = p.prefix + (td->prefix_rec0 + ((int64_t)e * S + s) * T + (t_begin - 1)) * REC;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+                const double keep = hasImg[q] ? 1.0 : 0.0;
+                const double *src = rec + (hasImg[q] ? cidx[q] : 0) * NP;
+#pragma unroll
+                for (int i = 0; i < NP; i += 2) {
+                    const double2 t2 = *reinterpret_cast<const double2 *>(src + i);
+                    col.v[q][i] = keep * t2.x;
+                    col.v[q][i + 1] = keep * t2.y;
+                }
+                if (!(isC[q] || isM[q])) {
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) col.v[q][i] = 0.0;
+                }
+                accq[q] = isM[q] ? rec[NC * NP + (cidx[q] - NP)] : 0.0;
+            }
+            P = rec[NC * NP + kDMax];
+            E = (int)rec[NC * NP + kDMax + 1];
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) px[q] += (int64_t)xstep[q] * t_begin;
+            if (!ALLVALID) pprobe += (int64_t)d * t_begin;
+            fetch(xn, pn); // frame t_begin (or the padding row)
+        } else {
+            fetch(xc, pc); // frame 0
+            fetch(xn, pn); // frame 1 (or the padding row)
+            if (ALLVALID || !isnan(pc)) update(xc);
+        }
+        // this launch builds the table: the state after every frame goes to its record (tasks have K1 = 1, s is fixed)
+        auto dump = [&](int t) {
+            double *__restrict__ rec = p.prefix_dump + (td->prefix_rec0 + ((int64_t)e * S + s) * T + t) * REC;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+                if (hasImg[q]) {
+#pragma unroll
+                    for (int i = 0; i < NP; i += 2)
+                        *reinterpret_cast<double2 *>(rec + cidx[q] * NP + i) = make_double2(col.v[q][i], col.v[q][i + 1]);
+                }
+                if (isM[q]) rec[NC * NP + (cidx[q] - NP)] = accq[q];
+            }
+            if (gl == 0) {
+                rec[NC * NP + kDMax] = P;
+                rec[NC * NP + kDMax + 1] = (double)E;
+            }
+        };
+        if constexpr (DUMP) dump(0);
+        for (int t = t_begin; t < T; ++t) {
 #pragma unroll
             for (int q = 0; q < CPL; ++q) xc[q] = xn[q];
             pc = pn;
             fetch(xn, pn); // frame t + 1 (<= T: the padding row at most)
             frame(t, xc, pc);
+            if constexpr (DUMP) dump(t);
         }
 
         // ---- sum of the per-frame log-densities (pyx:88, 251-256) ---------------------
@@ -520,7 +597,7 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
             for (int g2 = 0; g2 < G; ++g2) tot += scratch[g2];
             const double logS = log_once(P) + (double)E * kLn2;
             tot += (double)nd * (logS + (double)td->nvalid * kLog2Pi);
-            p.out[task] = -0.5 * tot;
+            p.out[otask] = -0.5 * tot;
         }
         wave_lds_fence();
     }
@@ -540,16 +617,22 @@ __global__ void reduce_partials_kernel(const double *__restrict__ partial, doubl
 // addressing in the likelihood kernels.  err[0] = first kind of violation seen (1 traj_id, 2 first start, 3 order of
 // starts, 4 state), err[1] = a sample that shows it.
 __global__ void validate_kernel(const int32_t *__restrict__ seg_start, const int32_t *__restrict__ seg_state,
-                                const int32_t *__restrict__ traj_id, int64_t n, int K1, int S, int n_traj, int *err)
+                                const int32_t *__restrict__ traj_id, const int32_t *__restrict__ order, int64_t n, int K1,
+                                int S, int n_traj, int *err)
 {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
     int bad = 0;
+    // order must be a permutation: in range, and every sample hit exactly once (err[2 + sample] counts the hits)
+    if (order) {
+        if (order[r] < 0 || order[r] >= n) bad = 5;
+        else if (atomicAdd(err + 2 + order[r], 1) != 0) bad = 5;
+    }
     if (traj_id && (traj_id[r] < 0 || traj_id[r] >= n_traj)) bad = 1;
     const int32_t *a = seg_start + r * K1, *b = seg_state + r * K1;
     if (!bad && a[0] != 0) bad = 2;
     for (int i = 0; i < K1 && !bad; ++i) {
-        if (i > 0 && a[i] < a[i - 1]) bad = 3;
+        if (i > 0 && (a[i] < a[i - 1] || a[i] < 1)) bad = 3;
         else if (b[i] < 0 || b[i] >= S) bad = 4;
     }
     if (bad && atomicCAS(err, 0, bad) == 0) err[1] = (int)(r < INT_MAX ? r : INT_MAX);
@@ -570,6 +653,17 @@ int launch_geom(int mode, const KParams &p, int grid, size_t lds, hipStream_t st
     // (rouse.Model is built with F = 0, models.py:246): keep it out of the common kernels
     // (and trajectories without a single missing frame out of the masked ones)
     const int flavor = p.has_G ? 0 : (p.all_valid ? 2 : 1);
+    if (p.prefix_dump) {
+        // the table is built by the packed one-column geometry with room for kDMax mean vectors
+        if constexpr (LAY == 0 && CPL == 1 && G == NP + kDMax) {
+            if (mode != kModal) return (int)hipErrorInvalidValue;
+            if (flavor == 0) return go(logl_kernel<NP, CPL, G, W, OCC, LAY, kModal, 0, true>);
+            if (flavor == 1) return go(logl_kernel<NP, CPL, G, W, OCC, LAY, kModal, 1, true>);
+            return go(logl_kernel<NP, CPL, G, W, OCC, LAY, kModal, 2, true>);
+        } else {
+            return (int)hipErrorInvalidValue;
+        }
+    }
     if (mode == kModal) {
         if (flavor == 0) return go(logl_kernel<NP, CPL, G, W, OCC, LAY, kModal, 0>);
         if (flavor == 1) return go(logl_kernel<NP, CPL, G, W, OCC, LAY, kModal, 1>);
@@ -693,6 +787,16 @@ bool geometry_for(int NP, int mode, int64_t ntasks, int means, Geometry *g)
     return true;
 }
 
+bool builder_geometry(int NP, Geometry *g)
+{
+    for (const Geometry &c : kGeoms)
+        if (c.NP == NP && c.CPL == 1 && c.G == NP + kDMax && c.id != 15 && c.id != 16 && c.id != 21 && c.id != 22) {
+            *g = c;
+            return true;
+        }
+    return false;
+}
+
 const char *kernel_name(const Geometry &, int mode) { return mode == kModal ? "logl_kernel<modal>" : "logl_kernel<dense>"; }
 
 int launch_logl(const Geometry &g, int mode, const KParams &p, int grid, size_t lds, void *stream)
@@ -707,12 +811,12 @@ int launch_logl(const Geometry &g, int mode, const KParams &p, int grid, size_t 
     }
 }
 
-int launch_validate(const int32_t *seg_start, const int32_t *seg_state, const int32_t *traj_id, int64_t n, int K1, int S,
-                    int n_traj, int *d_err, void *stream)
+int launch_validate(const int32_t *seg_start, const int32_t *seg_state, const int32_t *traj_id, const int32_t *order, int64_t n,
+                    int K1, int S, int n_traj, int *d_err, void *stream)
 {
     const int bs = 256;
     hipLaunchKernelGGL(validate_kernel, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, reinterpret_cast<hipStream_t>(stream),
-                       seg_start, seg_state, traj_id, n, K1, S, n_traj, d_err);
+                       seg_start, seg_state, traj_id, order, n, K1, S, n_traj, d_err);
     return (int)hipGetLastError();
 }
 

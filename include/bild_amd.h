@@ -52,6 +52,10 @@ typedef enum bild_status {
  * once before launching.  Without it the device entry trusts its input (the host-buffer entries always validate). */
 #define BILD_VALIDATE_DEVICE 0x10u
 
+/* Do not start candidates from the prefix table (see "prefix table" below): every task runs from frame 0.  Results are
+ * bit-identical either way; the flag exists for A/B measurements and tests.  (Environment BILD_NO_PREFIX=1: never build one.) */
+#define BILD_NO_PREFIX 0x20u
+
 /* bild_model_create flags */
 #define BILD_MODEL_NO_REDUCE 1u /* keep all N modes: skip the invariant-subspace reduction */
 
@@ -137,8 +141,9 @@ int bild_trajset_destroy(bild_trajset *ts);
  *
  * Profiles come run-length encoded, K1 segments per sample:
  *   segment i of sample r is in state seg_state[r*K1+i] and starts at frame
- *   seg_start[r*K1+i]; seg_start[r*K1+0] must be 0 and rows must be non-decreasing.
- *   Empty segments (equal starts, or a start >= T) are legal and skipped -- this is what
+ *   seg_start[r*K1+i]; seg_start[r*K1+0] must be 0, later starts >= 1 and non-decreasing (segment 0 owns
+ *   frame 0: it selects the steady state the filter starts from and is never empty).
+ *   Empty later segments (equal starts, or a start >= T) are legal and skipped -- this is what
  *   FixedkSampler.st2profile (bild/amis.py:685-693) produces for
  *   seg_start[1:] = floor(cumsum(s)[:-1]*(T-1)) + 1, seg_state = theta.
  *   state[0] selects the steady state the filter starts from, state[t] the propagator
@@ -193,6 +198,36 @@ int bild_logl_segments_device(const bild_model *m, const bild_trajset *ts, int64
                               const int32_t *d_seg_start, const int32_t *d_seg_state,
                               const int32_t *d_traj_id, unsigned flags, void *hip_stream,
                               double *d_out);
+
+/* ------------------------------------------------- prefix table and launch order -------
+ * Until its first switch a candidate's filter state depends only on (trajectory, localization-error chain, initial
+ * state, frame) -- not on the candidate.  At the first evaluation of a trajectory set on the modal path (chains of up to
+ * 32 modes) the library therefore runs the recursion once per (trajectory, chain, state) WITHOUT switches, keeps the state
+ * after every frame in HBM (T x S x d* records of ~1 KB; skipped when it would take more than a quarter of the free
+ * memory), and every candidate starts from the record in front of its first switch.  Same kernel, same arithmetic:
+ * results are bit-identical to running every candidate from frame 0 (BILD_NO_PREFIX).  One-time cost per trajectory
+ * set: one launch of about the duration of a single candidate, reported by bild_prefix_info.
+ *
+ * Candidates then differ in length, so the order in which they are dealt to wavefronts matters for speed (never for
+ * results).  The host-buffer entry points schedule internally.  For device-resident candidates the caller may obtain
+ * the launch order once (bild_schedule_segments, host arrays) and pass it, device-resident, to
+ * bild_logl_segments_device_ordered: order[slot] = index of the sample evaluated in slot `slot`; a permutation of
+ * 0..n-1 (checked only with BILD_VALIDATE_DEVICE).  NULL = the order of the arrays. */
+int bild_schedule_segments(const bild_model *m, const bild_trajset *ts, int64_t n, int K1,
+                           const int32_t *seg_start, const int32_t *traj_id /* may be NULL */,
+                           unsigned flags, int32_t *order /* out, n */);
+int bild_logl_segments_device_ordered(const bild_model *m, const bild_trajset *ts, int64_t n, int K1,
+                                      const int32_t *d_seg_start, const int32_t *d_seg_state,
+                                      const int32_t *d_traj_id, const int32_t *d_order,
+                                      unsigned flags, void *hip_stream, double *d_out);
+/* frames (task x frame pairs) of a batch, and how many of them the launch really runs when candidates start from the
+ * prefix table in the given launch order (host arrays; order may be NULL): the executed-operation count of a launch is
+ * bild_flop_count's `executed` times frames_run / frames_total */
+int bild_frames_executed(const bild_model *m, const bild_trajset *ts, int64_t n, int K1,
+                         const int32_t *seg_start, const int32_t *traj_id, const int32_t *order,
+                         unsigned flags, double *frames_total, double *frames_run);
+/* size of the table in bytes (0: none built) and the device time its construction took */
+int bild_prefix_info(const bild_trajset *ts, int64_t *bytes, double *build_ms);
 
 /* canonical floating-point operations of one batch,
  *   F = (T-1)(4 N^3 d* + 2 N^2 d) + Tv((4 N^2 + 3 N) d* + 4 N d)      

@@ -756,3 +756,158 @@ def test_st_seam_against_reference_vectors(built_lib):
         assert np.array_equal(a, b), (T, S)
         n += len(a)
     assert n > 1000
+
+
+def test_device_entry_rejects_bad_descriptors_when_asked(built_lib):
+    """
+    `bild_logl_segments_device` trusts device-resident descriptors unless BILD_VALIDATE_DEVICE is set; with the flag a
+    state >= S, a decreasing start, a first start != 0 or a trajectory id out of range comes back as an error instead of
+    driving an out-of-range access (nothing is launched for a rejected batch).
+    """
+    import torch
+    import bild_amd
+    from bild_amd import _lib
+    from bild_amd.profiles import segments_from_st
+    rng = np.random.default_rng(21)
+    model = bild_amd.MultiStateRouse(20, 1, 5, d=3, localization_error=0.1)
+    trajs = [model.trajectory_from_loopingprofile(H.random_profile(rng, 120, 2, 30), rng=rng) for _ in range(3)]
+    ss, thetas = H.candidate_profiles(rng, 500, 3, 2)
+    a, b = segments_from_st(ss, thetas, 120)
+    tid = rng.integers(3, size=500).astype(np.int32)
+    h, ts = model.handle(), model.trajset(trajs)
+    want = model.logL_segments(a, b, trajs, tid)
+    dev = torch.device('cuda', 0)
+    d_out = torch.full((500,), 7.0, dtype=torch.float64, device=dev)
+
+    def run(a_, b_, tid_, validate=True):
+        da, db, dt_ = (torch.from_numpy(np.ascontiguousarray(v)).to(dev) for v in (a_, b_, tid_))
+        _lib.logl_segments_device(h, ts, 500, 4, da.data_ptr(), db.data_ptr(), dt_.data_ptr(), d_out.data_ptr(),
+                                  stream=torch.cuda.current_stream().cuda_stream, validate=validate)
+        torch.cuda.synchronize()
+        return d_out.cpu().numpy()
+
+    assert np.array_equal(run(a, b, tid), want)
+    assert np.array_equal(run(a, b, tid, validate=False), want)
+    for what, (a2, b2, t2) in {
+        'state': (a, np.where(np.arange(500)[:, None] == 17, 2, b).astype(np.int32), tid),
+        'negative state': (a, np.where(np.arange(500)[:, None] == 3, -1, b).astype(np.int32), tid),
+        'order': (np.where((np.arange(500)[:, None] == 400) & (np.arange(4)[None, :] == 2), 0, a).astype(np.int32), b, tid),
+        'first start': (np.where((np.arange(500)[:, None] == 9) & (np.arange(4)[None, :] == 0), 1, a).astype(np.int32), b, tid),
+        'traj_id': (a, b, np.where(np.arange(500) == 250, 3, tid).astype(np.int32)),
+    }.items():
+        d_out.fill_(7.0)
+        with pytest.raises(_lib.BildAmdError) as info:
+            run(a2, b2, t2)
+        assert info.value.code == _lib.ERR_INVALID, what
+        assert np.all(d_out.cpu().numpy() == 7.0), what            # nothing ran
+
+
+def test_one_model_on_two_streams_with_distinct_errors(built_lib):
+    """
+    d* = 2 (localization errors that differ between dimensions) needs a buffer of partial results per launch; it belongs
+    to the call, so launches of ONE model on different streams, interleaved with host-entry calls, do not disturb each other.
+    """
+    import torch
+    import bild_amd
+    from bild_amd import _lib
+    from bild_amd.profiles import segments_from_st
+    rng = np.random.default_rng(22)
+    model = bild_amd.MultiStateRouse(20, 1, 5, d=3, localization_error=[0.1, 0.1, 0.3])
+    T = 400
+    traj = model.trajectory_from_loopingprofile(H.random_profile(rng, T, 2, 80), rng=rng)
+    h, ts = model.handle(), model.trajset(traj)
+    dev = torch.device('cuda', 0)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    batches = []
+    for i, n in enumerate((6000, 5000)):
+        ss, thetas = H.candidate_profiles(rng, n, 4, 2)
+        a, b = segments_from_st(ss, thetas, T)
+        batches.append((n, torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev),
+                        torch.empty(n, dtype=torch.float64, device=dev), model.logL_segments(a, b, traj), ss, thetas))
+    torch.cuda.synchronize()
+    for rep in range(4):
+        for (n, da, db, dout, want, ss, thetas), st in zip(batches, streams):
+            _lib.logl_segments_device(h, ts, n, 5, da.data_ptr(), db.data_ptr(), 0, dout.data_ptr(), stream=st.cuda_stream)
+        host = model.logL_st_batch(batches[0][5][:700], batches[0][6][:700], traj)   # host entry in between
+        torch.cuda.synchronize()
+        assert np.array_equal(host, batches[0][4][:700])
+        for n, da, db, dout, want, ss, thetas in batches:
+            assert np.array_equal(dout.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize('case', ['one_traj', 'many_traj_dstar2_missing', 'three_state'])
+def test_prefix_table_and_launch_order_do_not_change_results(built_lib, case):
+    """
+    Candidates start from the prefix table (state of the switch-free recursion in front of their first switch) and are
+    dealt to wavefronts in an order chosen by the host scheduler.  Both are matters of speed: every result must be
+    bit-identical to the run from frame 0 in array order (BILD_NO_PREFIX), through the host and the device entry points,
+    and equal to the oracle.  Includes profiles that never switch, first switches at frame 1, empty later segments.
+    """
+    import torch
+    import bild_amd
+    from bild_amd import _lib
+    from bild_amd.profiles import segments_from_st
+    rng = np.random.default_rng({'one_traj': 1, 'many_traj_dstar2_missing': 2, 'three_state': 3}[case])
+    if case == 'one_traj':
+        model = bild_amd.MultiStateRouse(20, 1, 5, d=3, localization_error=0.1)
+        Ts, n, k, S = [700], 9000, 4, 2
+        miss = [None]
+    elif case == 'many_traj_dstar2_missing':
+        model = bild_amd.MultiStateRouse(20, 1, 5, d=3, localization_error=[0.1, 0.25, 0.1])
+        Ts, n, k, S = [150, 333, 90, 611, 12], 7000, 3, 2
+        miss = [None, 0.1, [0, 1, 5], 0.3, None]
+    else:
+        model = bild_amd.MultiStateRouse(24, 1, 4, d=2, looppositions=H.LOOPS[3], localization_error=0.15)
+        Ts, n, k, S = [400, 250], 5000, 6, 3
+        miss = [0.05, None]
+    trajs = [model.trajectory_from_loopingprofile(H.random_profile(rng, T, S, max(T // 4, 2)), missing_frames=m_, rng=rng)
+             for T, m_ in zip(Ts, miss)]
+    tid = rng.integers(len(trajs), size=n).astype(np.int32)
+    ss, thetas = H.candidate_profiles(rng, n, k, S)
+    seg_start = np.zeros((n, k + 1), dtype=np.int32)
+    for j, T in enumerate(Ts):
+        sel = tid == j
+        seg_start[sel] = segments_from_st(ss[sel], thetas[sel], T)[0]
+    seg_state = thetas.astype(np.int32)
+    seg_start[:40, 1:] = np.int32(2 ** 31 - 1)       # never switch
+    seg_start[40:80, 1] = 1                          # first switch at frame 1
+    seg_start[80:120, 2] = seg_start[80:120, 1]      # an empty segment behind the first switch
+    seg_start[:, 1:] = np.sort(seg_start[:, 1:], axis=1)
+    h, ts = model.handle(), model.trajset(trajs)
+    base = _lib.logl_segments(h, ts, seg_start, seg_state, tid, prefix=False)
+    fast = _lib.logl_segments(h, ts, seg_start, seg_state, tid)
+    assert _lib.prefix_info(ts)[0] > 0                # a table was built
+    assert np.array_equal(fast, base)
+    # device entry: array order and scheduled order, with and without the table
+    dev = torch.device('cuda', 0)
+    order = _lib.schedule_segments(h, ts, seg_start, tid)
+    assert np.array_equal(np.sort(order), np.arange(n))
+    d = {name: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for name, v in
+         dict(a=seg_start, b=seg_state, t=tid, o=order).items()}
+    out = torch.empty(n, dtype=torch.float64, device=dev)
+    for d_order in (0, d['o'].data_ptr()):
+        for prefix in (True, False):
+            out.fill_(0.0)
+            _lib.logl_segments_device(h, ts, n, k + 1, d['a'].data_ptr(), d['b'].data_ptr(), d['t'].data_ptr(), out.data_ptr(),
+                                      stream=torch.cuda.current_stream().cuda_stream, d_order=d_order, prefix=prefix, validate=True)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), base), (d_order != 0, prefix)
+    # a launch order that is not a permutation is refused when validation is asked for
+    bad = order.copy()
+    bad[5] = bad[6]
+    d_bad = torch.from_numpy(bad).to(dev)
+    with pytest.raises(_lib.BildAmdError):
+        _lib.logl_segments_device(h, ts, n, k + 1, d['a'].data_ptr(), d['b'].data_ptr(), d['t'].data_ptr(), out.data_ptr(),
+                                  stream=torch.cuda.current_stream().cuda_stream, d_order=d_bad.data_ptr(), validate=True)
+    # segment 0 owns frame 0: a later segment may not start there
+    zero = seg_start.copy()
+    zero[3, 1] = 0
+    with pytest.raises(_lib.BildAmdError):
+        _lib.logl_segments(h, ts, zero, seg_state, tid)
+    # and against the oracle (the special rows above all among the checked ones)
+    pick = np.concatenate([np.arange(0, 120, 6), rng.choice(n, 30, replace=False)])
+    assert _spot_check(model, trajs, seg_start[pick], seg_state[pick], tid[pick], fast[pick], rng, len(pick), Ts) < TOL
+    # the share of frames the launch runs itself is what the scheduler promises: clearly below 1 with k switches
+    frac = _lib.frames_executed_fraction(h, ts, seg_start, tid, order)
+    assert 0.3 < frac < 0.97, frac
+    assert _lib.frames_executed_fraction(h, ts, seg_start, tid, order, prefix=False) == 1.0
