@@ -21,6 +21,7 @@ PATHS = {'auto': PATH_AUTO, 'dense': PATH_DENSE, 'modal': PATH_MODAL}
 MODEL_NO_REDUCE = 1
 VALIDATE_DEVICE = 0x10
 NO_PREFIX = 0x20
+NO_JUMP = 0x40
 
 Q_N, Q_D, Q_S, Q_MODAL_OK, Q_NP, Q_NEFF, Q_HAS_G = range(7)
 X_LAMBDA, X_SIGMA, X_Q, X_WQ, X_R, X_C0Q, X_V = range(7)
@@ -61,6 +62,7 @@ _SIGNATURES = {
     'bild_logl_segments_device_ordered': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, _vp, _vp, _vp, _vp,
                                                          ctypes.c_uint, _vp, _vp]),
     'bild_frames_executed': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, _ip, _ip, _ip, ctypes.c_uint, _dp, _dp]),
+    'bild_frames_run_read': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int64)]),
     'bild_prefix_info': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int64), _dp]),
     'bild_flop_count': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, _ip, ctypes.c_uint, _dp, _dp]),
     'bild_kernel_timing': (ctypes.c_int, [ctypes.c_int]),
@@ -215,18 +217,18 @@ class TrajSetHandle:
             self._h = None
 
 
-def logl_segments(model, ts, seg_start, seg_state, traj_id=None, path='auto', prefix=True):
+def logl_segments(model, ts, seg_start, seg_state, traj_id=None, path='auto', prefix=True, jump=True):
     seg_start, seg_state = i32(seg_start), i32(seg_state)
     n, K1 = seg_start.shape
     assert seg_state.shape == (n, K1)
     tid = None if traj_id is None else i32(traj_id)
     out = np.empty(n, dtype=np.float64)
     check(lib().bild_logl_segments(model._h, ts._h, n, K1, iptr(seg_start), iptr(seg_state), iptr(tid),
-                                   _flags(path, prefix=prefix), dptr(out)))
+                                   _flags(path, prefix=prefix, jump=jump), dptr(out)))
     return out
 
 
-def logl_st(model, ts, ss, thetas, traj_id=None, path='auto', prefix=True):
+def logl_st(model, ts, ss, thetas, traj_id=None, path='auto', prefix=True, jump=True):
     """ the sampler's (s, theta) batch as it is: switch frames are computed natively (bild_logl_st) """
     ss = f64(ss)
     thetas = np.ascontiguousarray(thetas, dtype=np.int64)
@@ -236,7 +238,7 @@ def logl_st(model, ts, ss, thetas, traj_id=None, path='auto', prefix=True):
     assert ss.shape == (n, K1)
     tid = None if traj_id is None else i32(traj_id)
     out = np.empty(n, dtype=np.float64)
-    check(lib().bild_logl_st(model._h, ts._h, n, K1, dptr(ss), thetas.ctypes.data_as(_vp), iptr(tid), _flags(path, prefix=prefix), dptr(out)))
+    check(lib().bild_logl_st(model._h, ts._h, n, K1, dptr(ss), thetas.ctypes.data_as(_vp), iptr(tid), _flags(path, prefix=prefix, jump=jump), dptr(out)))
     return out
 
 
@@ -275,8 +277,15 @@ def logl_profiles(model, ts, states, traj_id=None, path='auto'):
     return out
 
 
-def _flags(path, validate=False, prefix=True):
-    return PATHS[path] | (VALIDATE_DEVICE if validate else 0) | (0 if prefix else NO_PREFIX)
+def _flags(path, validate=False, prefix=True, jump=True):
+    return PATHS[path] | (VALIDATE_DEVICE if validate else 0) | (0 if prefix else NO_PREFIX) | (0 if jump else NO_JUMP)
+
+
+def frames_run_read(model):
+    """ frames the tasks ran themselves since the last call (kernel timing must be on); resets the counter """
+    v = ctypes.c_int64(0)
+    check(lib().bild_frames_run_read(model._h, ctypes.byref(v)))
+    return v.value
 
 
 def schedule_segments(model, ts, seg_start, traj_id=None, path='auto', prefix=True):
@@ -309,14 +318,14 @@ def prefix_info(ts):
 
 
 def logl_segments_device(model, ts, n, K1, d_seg_start, d_seg_state, d_traj_id, d_out, stream=0, path='auto', validate=False,
-                         d_order=0, prefix=True):
+                         d_order=0, prefix=True, jump=True):
     """
     raw device pointers (ints); asynchronous on `stream` (validate=True: descriptors checked on the device first);
     d_order: device pointer of the launch order from `schedule_segments`, 0 = the order of the arrays
     """
     check(lib().bild_logl_segments_device_ordered(model._h, ts._h, n, K1, _vp(d_seg_start), _vp(d_seg_state),
                                           _vp(d_traj_id) if d_traj_id else None, _vp(d_order) if d_order else None,
-                                          _flags(path, validate, prefix),
+                                          _flags(path, validate, prefix, jump),
                                           _vp(stream) if stream else None, _vp(d_out)))
 
 

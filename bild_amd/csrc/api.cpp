@@ -156,6 +156,7 @@ struct bild_model {
     mutable DeviceBuf ws_in, ws_out;
     mutable PinnedBuf h_in, h_out;
     mutable hipStream_t stream = nullptr;
+    mutable unsigned long long *d_frames = nullptr; // frames the tasks ran themselves, summed while kernel timing is on
     mutable hipEvent_t h_in_event = nullptr; // completion of the last copy out of h_in that nobody waited for
     mutable bool h_in_busy = false;
 };
@@ -170,7 +171,7 @@ struct bild_trajset {
     int Tmax = 0;
     bool all_valid = true;
     int device = -1;
-    double *d_x = nullptr; // all trajectories, each followed by one padding row, then kZeroPad zeros
+    double *d_x = nullptr; // all trajectories, each followed by kPadRows padding rows, then kZeroPad zeros
     double *d_zeros = nullptr;
     TrajDesc *d_descs = nullptr;
     // prefix table of the vector kernels' modal path (common.h: prefix_record_doubles), built at the first evaluation
@@ -512,6 +513,8 @@ int ensure_device(const bild_model &m)
     }
     HIP_TRY(hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&m.h_in_event, hipEventDisableTiming));
+    HIP_TRY(hipMalloc((void **)&m.d_frames, sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(m.d_frames, 0, sizeof(unsigned long long)));
     m.device = dev;
     return BILD_OK;
 }
@@ -660,6 +663,11 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
         if (mode == kModal && K1 > 0 && !(flags & BILD_NO_PREFIX)) {
             if (ts.prefix_state == 0) ensure_prefix(m, ts, st);
             if (ts.prefix_state == 1) p.prefix = ts.d_prefix;
+        }
+        p.no_jump = (flags & BILD_NO_JUMP) || getenv("BILD_NO_JUMP") ? 1 : 0;
+        {
+            std::lock_guard<std::mutex> lk(g_time_mu);
+            if (g_time_on) p.frames_run = m.d_frames;
         }
     }
     // d* > 1: one partial result per (sample, covariance chain), summed by a second kernel.  The buffer belongs to
@@ -902,6 +910,7 @@ int bild_model_destroy(bild_model *m)
     m->h_out.release();
     if (m->h_in_busy) (void)hipEventSynchronize(m->h_in_event);
     if (m->h_in_event) (void)hipEventDestroy(m->h_in_event);
+    if (m->d_frames) (void)hipFree(m->d_frames);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
     return BILD_OK;
@@ -975,8 +984,8 @@ int bild_trajset_create(const bild_model *m, int n_traj, const int32_t *T, const
     ts->descs.resize(n_traj);
 
     // device copy of the data: a frame with any NaN coordinate is missing (pyx:178) -> all NaN
-    // layout: per trajectory T rows + 1 padding row (the kernels fetch one frame ahead), then zeros
-    std::vector<double> xd((size_t)(total + n_traj) * d + kZeroPad, 0.0);
+    // layout: per trajectory T rows + kPadRows padding rows (the kernels fetch up to kPadRows frames ahead), then zeros
+    std::vector<double> xd((size_t)(total + (int64_t)kPadRows * n_traj) * d + kZeroPad, 0.0);
     const double qnan = std::nan("");
     int64_t off = 0;
     auto cleanup = [&](int code) {
@@ -987,21 +996,26 @@ int bild_trajset_create(const bild_model *m, int n_traj, const int32_t *T, const
     };
     hipError_t he = hipMalloc((void **)&ts->d_x, xd.size() * sizeof(double));
     if (he != hipSuccess) return cleanup(fail(BILD_ERR_NOMEM, "hipMalloc failed: %s", hipGetErrorString(he)));
-    ts->d_zeros = ts->d_x + (size_t)(total + n_traj) * d;
+    ts->d_zeros = ts->d_x + (size_t)(total + (int64_t)kPadRows * n_traj) * d;
     for (int j = 0; j < n_traj; ++j) {
         TrajDesc &td = ts->descs[j];
         std::memset(&td, 0, sizeof td);
         td.T = T[j];
-        const int64_t doff = off + j; // device row offset: j padding rows precede trajectory j
+        const int64_t doff = off + (int64_t)kPadRows * j; // device row offset: the padding rows of trajectories 0..j-1 precede
         td.x = ts->d_x + doff * d;
         int nvalid = 0;
+        double xscale = 0.0;
         for (int t = 0; t < T[j]; ++t) {
             bool valid = true;
             for (int k = 0; k < d; ++k) valid &= !std::isnan(x[(off + t) * d + k]);
-            for (int k = 0; k < d; ++k) xd[(doff + t) * d + k] = valid ? x[(off + t) * d + k] : qnan;
+            for (int k = 0; k < d; ++k) {
+                xd[(doff + t) * d + k] = valid ? x[(off + t) * d + k] : qnan;
+                if (valid && std::isfinite(x[(off + t) * d + k])) xscale = std::max(xscale, std::fabs(x[(off + t) * d + k]));
+            }
             nvalid += valid;
         }
         td.nvalid = nvalid;
+        td.xscale = xscale;
         ts->all_valid = ts->all_valid && nvalid == T[j];
         // np.unique(err, return_inverse=True): sorted unique values (pyx:145)
         double uniq[kDMax];
@@ -1155,6 +1169,19 @@ int bild_frames_executed(const bild_model *m, const bild_trajset *ts, int64_t n,
     }
     *frames_total = total;
     *frames_run = run;
+    return BILD_OK;
+}
+
+int bild_frames_run_read(const bild_model *m, int64_t *frames)
+{
+    if (!m || !frames) return fail(BILD_ERR_INVALID, "NULL argument");
+    *frames = 0;
+    if (!m->d_frames) return BILD_OK;
+    unsigned long long v = 0;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(&v, m->d_frames, sizeof v, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(m->d_frames, 0, sizeof v));
+    *frames = (int64_t)v;
     return BILD_OK;
 }
 

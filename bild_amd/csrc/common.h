@@ -6,6 +6,7 @@
 namespace bild {
 
 constexpr int kDMax = 3;      // spatial dimensions supported (reference default d = 3, models.py:222)
+constexpr int kPadRows = 4;   // rows behind each trajectory on the device: the frame loops fetch that many frames ahead
 constexpr int kMaxWaves = 4;  // wavefronts per workgroup (fewer for long chains: LDS capacity)
 constexpr int kMaxNP = 32;    // largest padded chain length with a register-resident kernel (kernels.hip)
 constexpr int kWideMaxNP = 128; // largest padded chain length at all: LDS-resident state (wide.hip), modal path only
@@ -33,7 +34,7 @@ struct StateBlock {
 constexpr int table_stride(int NP) { return NP * NP + 2; }
 
 struct TrajDesc {
-    const double *x; // device, (T + 1) x d: one padding row; every coordinate of a missing frame is NaN
+    const double *x; // device, (T + kPadRows) x d: padding rows behind the data; every coordinate of a missing frame is NaN
     int32_t T;
     int32_t dstar;           // number of distinct localization errors (pyx:145)
     double s2[kDMax];        // their squares, ascending
@@ -42,6 +43,7 @@ struct TrajDesc {
     int32_t nvalid;          // frames with data
     int32_t pad_;
     int64_t prefix_rec0;     // first record of this trajectory in the prefix table (records, see prefix_record_doubles)
+    double xscale;           // largest |coordinate| of the data: absolute floor of the mean-vector comparison
 };
 
 // Prefix table (vector kernels, modal path): the filter state after frame t of a task that has not switched yet
@@ -72,6 +74,9 @@ struct KParams {
     const int32_t *order;   // slot -> sample (launch order chosen by the host scheduler), null: identity
     const double *prefix;   // prefix table to start from, null: every task starts at frame 0
     double *prefix_dump;    // non-null: this launch BUILDS the table (one task per (trajectory, e, s), K1 = 1)
+    int32_t no_jump;        // with a prefix table: run every frame behind the first switch (no convergence jumps)
+    int32_t pad2_;
+    unsigned long long *frames_run; // non-null: tasks add the number of frames they ran themselves (bench accounting)
 };
 
 // launch geometry for a padded chain length

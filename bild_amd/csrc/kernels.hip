@@ -263,7 +263,11 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
         auto fetch = [&](double (&xv)[CPL], double &probe) {
 #pragma unroll
             for (int q = 0; q < CPL; ++q) {
+#ifdef BILD_X_NOLOAD // timing experiment only (wrong results): what the trajectory loads cost
+                xv[q] = 0.25;
+#else
                 xv[q] = *px[q];
+#endif
                 px[q] += xstep[q];
             }
             if (!ALLVALID) {
@@ -439,6 +443,7 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
             wave_lds_fence();
         };
 
+        int t_sw = INT_MIN / 2; // frame of the last change of state (drives the convergence checks below)
         // one frame t >= 1: state bookkeeping, predict (pyx:206-241), masked update (pyx:244-248)
         auto frame = [&](int t, const double (&xv)[CPL], double probe) {
             if (t >= next_start) {
@@ -451,6 +456,7 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
                     if (MODE == kModal) sandwich(const_cast<const double *>(smem) + (size_t)(sn * S + s) * MS, [] {});
                     s = sn;
                     load_state(s);
+                    t_sw = t;
                 }
             }
             if (MODE == kModal) {
@@ -497,43 +503,37 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
             if (ALLVALID || !isnan(probe)) update(xv);
         };
 
-        // ---- where to start.  Without a prefix table: frame 0, an update on the steady state without a predict
-        // (pyx:186-190).  With one: every task of this WAVE starts from the record in front of the earliest first switch
-        // among them (the host scheduler puts tasks with neighbouring first switches into one wave; a task whose own
-        // first switch comes later runs the few frames in between itself, in its initial state -- same arithmetic as
-        // the table's, so the result does not depend on where a task picks up).  Frames are fetched one ahead of
-        // their use. ------------------------------------------------------------------------------------------
+        // ---- where to start, and which frames to run at all ------------------------------------------------------
+        // Without a prefix table: frame 0 is an update on the steady state without a predict (pyx:186-190), then every
+        // frame.  With one, a task runs only where its filter differs from the switch-free filter of its current state:
+        //  * it STARTS from the record in front of its first switch;
+        //  * behind a switch the filter forgets where it came from at a geometric rate (a few tens of frames for a Rouse
+        //    chain).  Every kJumpEvery frames, from kJumpFirst frames behind the switch on, the task compares its whole
+        //    state [C | M] with the table's record of the same frame and state.  Equal states, same propagator and same
+        //    data give equal futures: once they agree to kJumpTol (relative to the largest entry of each column), the
+        //    task takes the table's sums up to its next switch, continues from the record in front of that switch, and
+        //    runs again from there.  No assumption about stationarity is made -- a task that never converges (long
+        //    gaps, slow modes) simply runs every frame.  The sums picked up from the table are differences of running
+        //    totals; together with the tolerance that makes a result deviate from the frame-by-frame one by ~1e-12
+        //    (bound in DESIGN.md; BILD_NO_JUMP runs every frame behind the first switch, bit-identical to BILD_NO_PREFIX).
+        // Rows of a wavefront are independent: each has its own frame counter and trajectory pointers.
         constexpr int NC = NP + kDMax;
         constexpr int REC = prefix_record_doubles(NP);
-        int t_begin = 1;
+#ifndef BILD_JUMP_FIRST
+#define BILD_JUMP_FIRST 24
+#endif
+#ifndef BILD_JUMP_EVERY
+#define BILD_JUMP_EVERY 8
+#endif
+        constexpr int kJumpFirst = BILD_JUMP_FIRST, kJumpEvery = BILD_JUMP_EVERY; // kJumpEvery: a power of two
+        constexpr double kJumpTol = 1.1368683772161603e-13; // 2^-43
         const bool restore = !DUMP && p.prefix != nullptr;
-        if (restore) {
-            // first frame this task may not take from the table; >= 1 (an empty first segment starts the table at frame 0)
-            const int mine = next_start < 1 ? 1 : (next_start < T ? next_start : T);
-            int tw = mine;
-            // minimum over the groups of this wave that have a task and a covariance chain to run
-            const int64_t wave_task0 = task - grp;
-#pragma unroll
-            for (int g2 = 0; g2 < GPW; ++g2) {
-                const int src_lane = BLK ? (g2 << 2) : g2 * G;
-                const int other = __builtin_amdgcn_readlane(mine, src_lane);
-                const int64_t t2 = wave_task0 + g2;
-                bool live = t2 < p.ntasks;
-                if (live) {
-                    const int64_t slot2 = t2 / p.dstar_max;
-                    const int64_t r2 = p.order ? p.order[slot2] : slot2;
-                    live = (int)(t2 - slot2 * p.dstar_max) < p.trajs[p.traj_id ? p.traj_id[r2] : 0].dstar;
-                }
-                if (live && other < tw) tw = other;
-            }
-            t_begin = __builtin_amdgcn_readfirstlane(tw); // the same in every lane that is still here
-        }
-        double xc[CPL], xn[CPL], pc, pn;
-        if (restore) {
-            const double *__restrict__ rec = p.prefix + (td->prefix_rec0 + ((int64_t)e * S + s) * T + (t_begin - 1)) * REC;
+        const bool jumping = restore && !p.no_jump;
+        auto record = [&](int t) { return p.prefix + (td->prefix_rec0 + ((int64_t)e * S + s) * T + t) * REC; };
+        auto load_cols = [&](const double *__restrict__ rec) {
 #pragma unroll
             for (int q = 0; q < CPL; ++q) {
-                const double keep = hasImg[q] ? 1.0 : 0.0;
+                const double keep = (isC[q] || isM[q]) ? 1.0 : 0.0;
                 const double *src = rec + (hasImg[q] ? cidx[q] : 0) * NP;
 #pragma unroll
                 for (int i = 0; i < NP; i += 2) {
@@ -541,26 +541,37 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
                     col.v[q][i] = keep * t2.x;
                     col.v[q][i + 1] = keep * t2.y;
                 }
-                if (!(isC[q] || isM[q])) {
-#pragma unroll
-                    for (int i = 0; i < NP; ++i) col.v[q][i] = 0.0;
-                }
-                accq[q] = isM[q] ? rec[NC * NP + (cidx[q] - NP)] : 0.0;
             }
+        };
+        // lanes of this task, as a mask over the wavefront (for the row-wide verdict of a comparison)
+        unsigned long long group_mask;
+        if (BLK) group_mask = 0x000F000F000F000Full << (4 * grp);
+        else group_mask = (G == 64 ? ~0ull : ((1ull << G) - 1)) << (grp * G);
+
+        int t = 1;
+        int nrun = 0;
+        double xc[CPL], xn[CPL], pc, pn;
+        if (restore) {
+            // first frame this task may not take from the table; >= 1 (segment 0 owns frame 0)
+            t = next_start < 1 ? 1 : (next_start < T ? next_start : T);
+            const double *__restrict__ rec = record(t - 1);
+            load_cols(rec);
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) accq[q] = isM[q] ? rec[NC * NP + (cidx[q] - NP)] : 0.0;
             P = rec[NC * NP + kDMax];
             E = (int)rec[NC * NP + kDMax + 1];
 #pragma unroll
-            for (int q = 0; q < CPL; ++q) px[q] += (int64_t)xstep[q] * t_begin;
-            if (!ALLVALID) pprobe += (int64_t)d * t_begin;
-            fetch(xn, pn); // frame t_begin (or the padding row)
+            for (int q = 0; q < CPL; ++q) px[q] += (int64_t)xstep[q] * t;
+            if (!ALLVALID) pprobe += (int64_t)d * t;
+            fetch(xn, pn); // frame t (or the first padding row)
         } else {
             fetch(xc, pc); // frame 0
-            fetch(xn, pn); // frame 1 (or the padding row)
+            fetch(xn, pn); // frame 1 (or the first padding row)
             if (ALLVALID || !isnan(pc)) update(xc);
         }
         // this launch builds the table: the state after every frame goes to its record (tasks have K1 = 1, s is fixed)
-        auto dump = [&](int t) {
-            double *__restrict__ rec = p.prefix_dump + (td->prefix_rec0 + ((int64_t)e * S + s) * T + t) * REC;
+        auto dump = [&](int tt) {
+            double *__restrict__ rec = p.prefix_dump + (td->prefix_rec0 + ((int64_t)e * S + s) * T + tt) * REC;
 #pragma unroll
             for (int q = 0; q < CPL; ++q) {
                 if (hasImg[q]) {
@@ -576,14 +587,58 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
             }
         };
         if constexpr (DUMP) dump(0);
-        for (int t = t_begin; t < T; ++t) {
+        while (t < T) {
+            // invariant: xn holds frame t, the pointers stand at frame t + 1
 #pragma unroll
             for (int q = 0; q < CPL; ++q) xc[q] = xn[q];
             pc = pn;
-            fetch(xn, pn); // frame t + 1 (<= T: the padding row at most)
+            fetch(xn, pn);
             frame(t, xc, pc);
             if constexpr (DUMP) dump(t);
+            ++t;
+            ++nrun;
+            if (jumping && t < T) {
+                const int dt = t - t_sw;
+                if (dt >= kJumpFirst && (dt & (kJumpEvery - 1)) == 0) {
+                    const double *__restrict__ rec = record(t - 1);
+                    bool same = true;
+#pragma unroll
+                    for (int q = 0; q < CPL; ++q) {
+                        if (!hasImg[q]) continue;
+                        double dev = 0.0, ref = isM[q] ? td->xscale : 0.0;
+#pragma unroll
+                        for (int i = 0; i < NP; i += 2) {
+                            const double2 r2 = *reinterpret_cast<const double2 *>(rec + cidx[q] * NP + i);
+                            dev = fmax(dev, fmax(fabs(col.v[q][i] - r2.x), fabs(col.v[q][i + 1] - r2.y)));
+                            ref = fmax(ref, fmax(fabs(r2.x), fabs(r2.y)));
+                        }
+                        same = same && (dev <= kJumpTol * ref); // a NaN anywhere never compares equal
+                    }
+                    const unsigned long long agree = __ballot(same);
+                    if ((agree & group_mask) == group_mask) {
+                        const int t2 = next_start < T ? next_start : T;
+                        if (t2 > t) {
+                            const double *__restrict__ rec2 = record(t2 - 1);
+#pragma unroll
+                            for (int q = 0; q < CPL; ++q)
+                                if (isM[q]) accq[q] += rec2[NC * NP + (cidx[q] - NP)] - rec[NC * NP + (cidx[q] - NP)];
+                            int ex;
+                            P = frexp(P * (rec2[NC * NP + kDMax] / rec[NC * NP + kDMax]), &ex);
+                            E += ex + ((int)rec2[NC * NP + kDMax + 1] - (int)rec[NC * NP + kDMax + 1]);
+                            if (t2 < T) {
+                                load_cols(rec2);
+#pragma unroll
+                                for (int q = 0; q < CPL; ++q) px[q] += (int64_t)xstep[q] * (t2 - t - 1);
+                                if (!ALLVALID) pprobe += (int64_t)d * (t2 - t - 1);
+                                fetch(xn, pn); // frame t2
+                            }
+                            t = t2;
+                        }
+                    }
+                }
+            }
         }
+        if (p.frames_run && gl == 0) atomicAdd(p.frames_run, (unsigned long long)nrun);
 
         // ---- sum of the per-frame log-densities (pyx:88, 251-256) ---------------------
         double acc = 0.0;

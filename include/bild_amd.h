@@ -56,6 +56,11 @@ typedef enum bild_status {
  * bit-identical either way; the flag exists for A/B measurements and tests.  (Environment BILD_NO_PREFIX=1: never build one.) */
 #define BILD_NO_PREFIX 0x20u
 
+/* With a prefix table: do not take the table's sums where a candidate's filter has converged onto the switch-free one
+ * (see "prefix table" below); every frame behind the first switch is run.  Bit-identical to BILD_NO_PREFIX.
+ * (Environment BILD_NO_JUMP=1: the same for every call.) */
+#define BILD_NO_JUMP 0x40u
+
 /* bild_model_create flags */
 #define BILD_MODEL_NO_REDUCE 1u /* keep all N modes: skip the invariant-subspace reduction */
 
@@ -208,6 +213,14 @@ int bild_logl_segments_device(const bild_model *m, const bild_trajset *ts, int64
  * results are bit-identical to running every candidate from frame 0 (BILD_NO_PREFIX).  One-time cost per trajectory
  * set: one launch of about the duration of a single candidate, reported by bild_prefix_info.
  *
+ * Behind a switch a Kalman filter forgets its starting point at a geometric rate: after a few tens of frames the
+ * candidate's state [C | M] agrees with the table's record of the same frame and state to rounding.  The kernel checks
+ * exactly that (whole state, every 8 frames from 24 frames behind the switch, relative tolerance 2^-43 per column) and,
+ * once it holds, takes the table's sums up to the candidate's next switch and continues from the record in front of
+ * it: equal state + same propagator + same data = same future.  Nothing is assumed about stationarity; a candidate
+ * that does not converge runs every frame.  This changes results by ~1e-12 (differences of running sums, tolerance of
+ * the comparison); BILD_NO_JUMP switches it off.  A result never depends on the other candidates of the batch.
+ *
  * Candidates then differ in length, so the order in which they are dealt to wavefronts matters for speed (never for
  * results).  The host-buffer entry points schedule internally.  For device-resident candidates the caller may obtain
  * the launch order once (bild_schedule_segments, host arrays) and pass it, device-resident, to
@@ -226,6 +239,9 @@ int bild_logl_segments_device_ordered(const bild_model *m, const bild_trajset *t
 int bild_frames_executed(const bild_model *m, const bild_trajset *ts, int64_t n, int K1,
                          const int32_t *seg_start, const int32_t *traj_id, const int32_t *order,
                          unsigned flags, double *frames_total, double *frames_run);
+/* frames the tasks of all launches of this model ran themselves since the last call (counted on the device while
+ * bild_kernel_timing is enabled; the rest came out of the prefix table); resets the counter; synchronises the device */
+int bild_frames_run_read(const bild_model *m, int64_t *frames);
 /* size of the table in bytes (0: none built) and the device time its construction took */
 int bild_prefix_info(const bild_trajset *ts, int64_t *bytes, double *build_ms);
 

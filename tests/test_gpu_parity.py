@@ -875,10 +875,14 @@ def test_prefix_table_and_launch_order_do_not_change_results(built_lib, case):
     seg_start[:, 1:] = np.sort(seg_start[:, 1:], axis=1)
     h, ts = model.handle(), model.trajset(trajs)
     base = _lib.logl_segments(h, ts, seg_start, seg_state, tid, prefix=False)
-    fast = _lib.logl_segments(h, ts, seg_start, seg_state, tid)
+    exact = _lib.logl_segments(h, ts, seg_start, seg_state, tid, jump=False)     # table as starting point only
+    fast = _lib.logl_segments(h, ts, seg_start, seg_state, tid)                  # + convergence jumps (the default)
     assert _lib.prefix_info(ts)[0] > 0                # a table was built
-    assert np.array_equal(fast, base)
-    # device entry: array order and scheduled order, with and without the table
+    assert np.array_equal(exact, base)
+    jump_dev = np.max(np.abs(fast - base))
+    print(f"{case}: max |jumping - frame by frame| = {jump_dev:.2e} on |logL| up to {np.max(np.abs(base)):.1e}")
+    assert jump_dev < 1e-9
+    # device entry: array order and scheduled order, with and without the table / the jumps
     dev = torch.device('cuda', 0)
     order = _lib.schedule_segments(h, ts, seg_start, tid)
     assert np.array_equal(np.sort(order), np.arange(n))
@@ -886,12 +890,16 @@ def test_prefix_table_and_launch_order_do_not_change_results(built_lib, case):
          dict(a=seg_start, b=seg_state, t=tid, o=order).items()}
     out = torch.empty(n, dtype=torch.float64, device=dev)
     for d_order in (0, d['o'].data_ptr()):
-        for prefix in (True, False):
+        for prefix, jump, want in ((True, False, base), (False, True, base), (True, True, fast)):
             out.fill_(0.0)
             _lib.logl_segments_device(h, ts, n, k + 1, d['a'].data_ptr(), d['b'].data_ptr(), d['t'].data_ptr(), out.data_ptr(),
-                                      stream=torch.cuda.current_stream().cuda_stream, d_order=d_order, prefix=prefix, validate=True)
+                                      stream=torch.cuda.current_stream().cuda_stream, d_order=d_order, prefix=prefix, jump=jump,
+                                      validate=True)
             torch.cuda.synchronize()
-            assert np.array_equal(out.cpu().numpy(), base), (d_order != 0, prefix)
+            # a result depends on its own candidate only: never on the launch order or on the rest of the batch
+            assert np.array_equal(out.cpu().numpy(), want), (d_order != 0, prefix, jump)
+    half = rng.permutation(n)[:n // 3]
+    assert np.array_equal(_lib.logl_segments(h, ts, seg_start[half], seg_state[half], tid[half]), fast[half])
     # a launch order that is not a permutation is refused when validation is asked for
     bad = order.copy()
     bad[5] = bad[6]
@@ -907,7 +915,15 @@ def test_prefix_table_and_launch_order_do_not_change_results(built_lib, case):
     # and against the oracle (the special rows above all among the checked ones)
     pick = np.concatenate([np.arange(0, 120, 6), rng.choice(n, 30, replace=False)])
     assert _spot_check(model, trajs, seg_start[pick], seg_state[pick], tid[pick], fast[pick], rng, len(pick), Ts) < TOL
-    # the share of frames the launch runs itself is what the scheduler promises: clearly below 1 with k switches
-    frac = _lib.frames_executed_fraction(h, ts, seg_start, tid, order)
-    assert 0.3 < frac < 0.97, frac
-    assert _lib.frames_executed_fraction(h, ts, seg_start, tid, order, prefix=False) == 1.0
+    # frames the tasks ran themselves (counted on the device): all of them without the table, a fraction with it
+    total = float(np.sum(np.asarray(Ts)[tid])) * (2 if case == 'many_traj_dstar2_missing' else 1)
+    shares = {}
+    for name, kw in (('frame by frame', dict(prefix=False)), ('table', dict(jump=False)), ('table + jumps', {})):
+        _lib.kernel_timing(True)
+        _lib.logl_segments(h, ts, seg_start, seg_state, tid, **kw)
+        _lib.kernel_timing(False)
+        _lib.kernel_timing_read()
+        shares[name] = _lib.frames_run_read(h) / total
+    print(case, {k_: round(v, 3) for k_, v in shares.items()})
+    assert 0.97 < shares['frame by frame'] <= 1.0          # frame 0 is not counted
+    assert shares['table + jumps'] < shares['table'] < shares['frame by frame']

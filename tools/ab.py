@@ -25,7 +25,8 @@ def build(specs):
         name, _, flags = spec.partition(':')
         out = os.path.join(VDIR, f'libbild_amd_{name}.so')
         cmd = ['hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-shared'] + flags.split() + \
-              [os.path.join(CSRC, 'api.cpp'), os.path.join(CSRC, 'kernels.hip'), '-o', out]
+              [os.path.join(CSRC, f) for f in ('api.cpp', 'amis_host.cpp', 'kernels.hip', 'wide.hip', 'dense_mfma.hip',
+                                               'modal_mfma.hip')] + ['-o', out]
         procs.append((name, subprocess.Popen(cmd)))
     for name, p in procs:
         if p.wait() != 0:
@@ -51,7 +52,7 @@ def run(argv):
             if g != '':
                 env['BILD_GEOM'] = g
             cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '30', '--warmup', '3', '--no-cpu-baseline',
-                   '--no-dense', '--samples', ns] + extra
+                   '--no-secondary', '--samples', ns] + extra
             r = subprocess.run(cmd, env=env, capture_output=True, text=True)
             line = [l for l in r.stdout.splitlines() if l.startswith('{')]
             if not line:
@@ -59,7 +60,7 @@ def run(argv):
                 continue
             j = json.loads(line[-1])
             print(f"{v[12:-3] + ('/g' + g if g else ''):28s} n={ns:>7s} value={j['value'] / 1e6:8.3f} M/s  kernel={j['roofline']['kernel_ms'] * 1e3:9.1f} us"
-                  f"  exec_frac={j['roofline']['executed_frac']:.3f}", flush=True)
+                  f"  frac={j['roofline']['frac']:.3f}  seam={j['api_seam']['value'] / 1e6:7.3f} M/s", flush=True)
 
 
 if __name__ == '__main__':
