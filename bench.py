@@ -263,6 +263,7 @@ def main():
         dt = time.perf_counter() - t0
         _lib.kernel_timing(False)
         kms, launches, kname = _lib.kernel_timing_read()
+        timed.frames_per_launch = _lib.frames_run_read(h) / max(launches, 1)   # counted on the device by the tasks themselves
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == 'nccl' else 'cpu')
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -271,6 +272,8 @@ def main():
 
     dt, kernel_ms, kname = timed(lambda: step(args.path), args.steps, args.warmup)
     value = n_global * args.steps / dt
+    frames_total = float(sum(len(trajs[j]) for j in (traj_id if traj_id is not None else np.zeros(n, dtype=int))))
+    frames_frac = timed.frames_per_launch / frames_total
 
     # ---- roofline of the dominant kernel: executed operations against the fp64 vector peak --------------------
     traffic = None
@@ -282,7 +285,6 @@ def main():
     except Exception:
         pass
     can, exe = _lib.flop_count(h, ts, n, traj_id=traj_id, path=args.path)
-    frames_frac = _lib.frames_executed_fraction(h, ts, seg_start, traj_id, order, path=args.path)
     exe *= frames_frac
     prefix_bytes, prefix_ms = _lib.prefix_info(ts)
     ksec = kernel_ms * 1e-3
@@ -298,10 +300,12 @@ def main():
         'flops_basis': 'operations the kernel executes: modal recursion on the reduced chain, frames actually run',
         'flop_per_eval_executed': exe / n,
         'frames_executed_fraction': frames_frac,
+        'frames_note': 'share of the (candidate, frame) pairs the launch ran itself, counted on the device; the rest comes out '
+                       'of the prefix table: a candidate starts at its first switch and, once its filter state agrees with '
+                       'the switch-free one behind a switch, takes the table\'s sums up to its next switch',
         'prefix_table': {'bytes': prefix_bytes, 'build_ms_once_per_trajectory_set': prefix_ms,
-                         'note': 'filter states before any switch, per (trajectory, state, frame): built once per trajectory '
-                                 'set by the likelihood kernel itself, outside the timed region like the upload of the '
-                                 'trajectory; candidates start at their first switch (bit-identical results)'},
+                         'note': 'switch-free filter states per (trajectory, state, frame): built once per trajectory set by '
+                                 'the likelihood kernel itself, outside the timed region like the upload of the trajectory'},
         'kernel_ms': kernel_ms,
         'traffic': traffic,
         'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC passes, gfx950 correction applied; profiles/r02_hbm_traffic.json)',
@@ -357,7 +361,7 @@ def main():
             ndt, nkms, nname = timed(lambda: step(args.path, prefix=False), reps, 1)
             _, nexe = _lib.flop_count(h, ts, n, traj_id=traj_id, path=args.path)
             result['without_prefix_table'] = {
-                'what': 'the same batch with every candidate run from frame 0 (BILD_NO_PREFIX, array order)',
+                'what': 'the same batch with every candidate run frame by frame from frame 0 (BILD_NO_PREFIX, array order)',
                 'value': n * reps / ndt, 'unit': 'evals/s', 'kernel': nname, 'kernel_ms': nkms,
                 'achieved': nexe / (nkms * 1e-3) / 1e12, 'frac': nexe / (nkms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
             }

@@ -63,6 +63,7 @@ _SIGNATURES = {
                                                          ctypes.c_uint, _vp, _vp]),
     'bild_frames_executed': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, _ip, _ip, _ip, ctypes.c_uint, _dp, _dp]),
     'bild_frames_run_read': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int64)]),
+    'bild_debug_frames_per_task': (ctypes.c_int, [_vp]),
     'bild_prefix_info': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int64), _dp]),
     'bild_flop_count': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, _ip, ctypes.c_uint, _dp, _dp]),
     'bild_kernel_timing': (ctypes.c_int, [ctypes.c_int]),

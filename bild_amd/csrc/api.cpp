@@ -9,6 +9,7 @@
 #include <cstring>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <queue>
 #include <new>
@@ -112,6 +113,7 @@ struct PinnedBuf {
 };
 
 // kernel timing (bench.py roofline leg)
+std::atomic<int32_t *> g_frames_task{nullptr}; // diagnostics: bild_debug_frames_per_task
 std::mutex g_time_mu;
 bool g_time_on = false;
 std::vector<std::pair<hipEvent_t, hipEvent_t>> g_time_events;
@@ -143,6 +145,7 @@ struct bild_model {
     bool wide = false; // NP > kMidMaxNP: LDS-resident kernel (wide.hip), modal path only
     bool mid = false;  // kMaxNP < NP <= kMidMaxNP: tile-register kernel (modal_mfma.hip), modal path only
     bool symmetric = true; // B, Sig, C0 symmetric (what the reference's dsymv calls assume)
+    bool tab_factored = false; // modal table of the vector kernels holds Q[s], Q[s]^T instead of all pairs R[s2][s]
     Mat blob_states[2], blob_tab[2];
     // device residency
     mutable std::mutex mu;      // device residency and workspace growth
@@ -441,6 +444,9 @@ int analyse(bild_model &m)
         }
     }
     m.NPm[kModal] = m.NP;
+    // register-resident kernels keep the basis-change matrices in LDS: all S*S pairs while that stays small
+    // (two workgroups' worth of product images must still fit beside them), else the 2 S factors Q[s], Q[s]^T
+    m.tab_factored = !m.wide && !m.mid && m.modal_ok && (size_t)S * S * table_stride(m.NP) * sizeof(double) > (size_t)32 * 1024;
     // the matrix-pipe kernel reads tiles transposed and relies on B, Sig, C0 being symmetric
     m.NPm[kDense] = (!m.wide && !m.mid && m.symmetric && dense_mfma_supported((n + 3) & ~3)) ? ((n + 3) & ~3) : m.NP;
     for (int mode = 0; mode < 2; ++mode) {
@@ -481,6 +487,16 @@ int analyse(bild_model &m)
                 put(s, m.rB.data() + (size_t)s * n * n);
                 put(S + s, m.rSig.data() + (size_t)s * n * n);
             }
+        } else if (m.tab_factored) {
+            // many states: S*S basis changes R[s2][s] = Q[s2]^T Q[s] would not fit LDS; keep the 2 S factors instead
+            // (slot s: Q[s], modal -> common coordinates; slot S + s: Q[s]^T, back) and change basis in two steps
+            tb.assign((size_t)2 * S * MS, 0.0);
+            for (int s = 0; s < S; ++s) {
+                Mat Q(m.Q.begin() + (size_t)s * n * n, m.Q.begin() + (size_t)(s + 1) * n * n);
+                Mat Qt = la::transpose(Q, n, n);
+                put(s, Q.data());
+                put(S + s, Qt.data());
+            }
         } else {
             for (int s2 = 0; s2 < S; ++s2)
                 for (int s = 0; s < S; ++s) put(s2 * S + s, m.R.data() + ((size_t)s2 * S + s) * n * n);
@@ -493,8 +509,8 @@ size_t lds_bytes(const bild_model &m, const Geometry &geom, int mode)
 {
     // matrix tables (dense: B_s, Sig_s; modal: basis changes R) + per-group product images
     const size_t groups = (size_t)geom.W * (64 / geom.G);
-    const size_t image = (size_t)group_image_doubles(geom.NP);
-    return (m.blob_tab[mode].size() + groups * image) * sizeof(double);
+    const size_t image = (size_t)group_image_doubles(geom.NP) + group_seg_doubles();
+    return (m.blob_tab[mode].size() + (size_t)m.S * state_header_doubles(geom.NP) + groups * image) * sizeof(double);
 }
 
 int ensure_device(const bild_model &m)
@@ -513,8 +529,8 @@ int ensure_device(const bild_model &m)
     }
     HIP_TRY(hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&m.h_in_event, hipEventDisableTiming));
-    HIP_TRY(hipMalloc((void **)&m.d_frames, sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(m.d_frames, 0, sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc((void **)&m.d_frames, kFrameCounters * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(m.d_frames, 0, kFrameCounters * sizeof(unsigned long long)));
     m.device = dev;
     return BILD_OK;
 }
@@ -544,6 +560,7 @@ int fill_params(const bild_model &m, const bild_trajset &ts, int mode, KParams &
     p.trajs = ts.d_descs;
     p.dstar_max = ts.dstar_max;
     p.zeros = ts.d_zeros;
+    p.tab_factored = (mode == kModal && m.tab_factored) ? 1 : 0;
     return BILD_OK;
 }
 
@@ -648,7 +665,7 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
             return fail(BILD_ERR_UNSUPPORTED, "no kernel for %d rows", m.NPm[mode]);
         lds = lds_bytes(m, geom, mode);
         if (lds > 160 * 1024)
-            return fail(BILD_ERR_UNSUPPORTED, "model tables need %zu bytes of LDS (> 160 KiB): too many states for chain length %d", lds, m.n);
+            return fail(BILD_ERR_UNSUPPORTED, "model tables need %zu bytes of LDS (> 160 KiB): too many states (%d) for chain length %d", lds, m.S, m.n);
     }
 
     KParams p{};
@@ -669,6 +686,7 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
             std::lock_guard<std::mutex> lk(g_time_mu);
             if (g_time_on) p.frames_run = m.d_frames;
         }
+        p.frames_task = g_frames_task.load();
     }
     // d* > 1: one partial result per (sample, covariance chain), summed by a second kernel.  The buffer belongs to
     // THIS call (stream-ordered allocation, released behind the reduction): launches of one model on different
@@ -792,6 +810,21 @@ bool schedule(const bild_model &m, const bild_trajset &ts, int64_t n, int K1, co
 // pinned staging memory (and validates them: these indices drive device addressing); then ONE host-to-device copy of
 // the packed block [seg_start | seg_state | traj_id], the launch, one device-to-host copy of the results, one
 // synchronisation -- all on the model's own stream.
+// BILD_TRACE_STAGED=1: print where a host-buffer call spends its time (microseconds), every 64th call
+struct StageClock {
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    StageClock() : on(getenv("BILD_TRACE_STAGED") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    void lap(int i)
+    {
+        if (!on) return;
+        auto t1 = std::chrono::steady_clock::now();
+        acc[i] += std::chrono::duration<double, std::micro>(t1 - t0).count();
+        t0 = t1;
+    }
+};
+
 template <typename Fill>
 int run_staged(const bild_model *m, const bild_trajset *ts, int64_t n, int K1, const int32_t *traj_id, unsigned flags,
                double *out, double *d_out_user, hipStream_t st_user, Fill &&fill)
@@ -816,11 +849,14 @@ int run_staged(const bild_model *m, const bild_trajset *ts, int64_t n, int K1, c
             if ((rc = m->ws_out.reserve((size_t)n * sizeof(double)))) return rc;
         }
     }
+    StageClock clk;
     int32_t *h_start = (int32_t *)m->h_in.ptr, *h_state = h_start + nseg, *h_tid = h_state + nseg;
     int32_t *h_order = h_tid + (traj_id ? n : 0);
     if ((rc = fill(h_start, h_state))) return rc;
     if (traj_id) std::memcpy(h_tid, traj_id, (size_t)n * sizeof(int32_t));
+    clk.lap(0);
     const bool ordered = schedule(*m, *ts, n, K1, h_start, traj_id, flags, h_order);
+    clk.lap(1);
     const size_t in_bytes = (2 * nseg + (traj_id ? (size_t)n : 0) + (ordered ? (size_t)n : 0)) * sizeof(int32_t);
     int32_t *d_start = (int32_t *)m->ws_in.ptr, *d_state = d_start + nseg, *d_tid = traj_id ? d_state + nseg : nullptr;
     const int32_t *d_order = ordered ? d_state + nseg + (traj_id ? n : 0) : nullptr;
@@ -837,9 +873,18 @@ int run_staged(const bild_model *m, const bild_trajset *ts, int64_t n, int K1, c
         return rc;
     }
     if (d_out_user) return BILD_OK; // results stay in HBM, ordered on the caller's stream
+    clk.lap(2);
     HIP_TRY(hipMemcpyAsync(m->h_out.ptr, d_out, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    clk.lap(3);
     std::memcpy(out, m->h_out.ptr, (size_t)n * sizeof(double));
+    clk.lap(4);
+    if (clk.on) {
+        static int calls = 0;
+        if ((calls++ & 63) == 0)
+            fprintf(stderr, "[bild staged n=%lld] fill %.1f  schedule %.1f  enqueue(H2D+launch) %.1f  wait(kernel+D2H) %.1f  copy out %.1f us\n",
+                    (long long)n, clk.acc[0], clk.acc[1], clk.acc[2], clk.acc[3], clk.acc[4]);
+    }
     return BILD_OK;
 }
 
@@ -870,7 +915,7 @@ int bild_model_create(int N, int d, int S, const double *B, const double *G, con
     *out = nullptr;
     if (!B || !G || !Sig || !M0 || !C0 || !w) return fail(BILD_ERR_INVALID, "NULL model array");
     if (N < 1 || S < 1) return fail(BILD_ERR_INVALID, "need N >= 1 and S >= 1 (got N=%d, S=%d)", N, S);
-    if (d < 1 || d > kDMax) return fail(BILD_ERR_UNSUPPORTED, "spatial dimension d=%d outside 1..%d", d, kDMax);
+    if (d < 1 || d > kDStore) return fail(BILD_ERR_UNSUPPORTED, "spatial dimension d=%d outside 1..%d", d, kDStore);
     if (S > 255) return fail(BILD_ERR_UNSUPPORTED, "S=%d states exceed 255", S);
     const size_t nn = (size_t)S * N * N, nd = (size_t)S * N * d;
     if (!all_finite(B, nn) || !all_finite(Sig, nn) || !all_finite(C0, nn) || !all_finite(G, nd) || !all_finite(M0, nd) ||
@@ -1018,7 +1063,7 @@ int bild_trajset_create(const bild_model *m, int n_traj, const int32_t *T, const
         td.xscale = xscale;
         ts->all_valid = ts->all_valid && nvalid == T[j];
         // np.unique(err, return_inverse=True): sorted unique values (pyx:145)
-        double uniq[kDMax];
+        double uniq[kDStore];
         int nu = 0;
         for (int k = 0; k < d; ++k) {
             const double e = loc_err[(size_t)j * d + k];
@@ -1027,16 +1072,26 @@ int bild_trajset_create(const bild_model *m, int n_traj, const int32_t *T, const
             if (!seen) uniq[nu++] = e;
         }
         std::sort(uniq, uniq + nu);
-        td.dstar = nu;
+        // one covariance chain per distinct error; a task carries at most kDMax mean vectors, so an error shared by
+        // more dimensions than that gets several chains (the covariance recursion is simply repeated)
+        int nchains = 0;
         for (int u = 0; u < nu; ++u) {
-            td.s2[u] = uniq[u] * uniq[u];
-            td.ndims[u] = 0;
+            int in_chain = kDMax; // forces a new chain at the first dimension
+            for (int k = 0; k < d; ++k) {
+                if (loc_err[(size_t)j * d + k] != uniq[u]) continue;
+                if (in_chain == kDMax) {
+                    td.s2[nchains] = uniq[u] * uniq[u];
+                    td.ndims[nchains] = 0;
+                    ++nchains;
+                    in_chain = 0;
+                }
+                td.dims[nchains - 1][td.ndims[nchains - 1]++] = k;
+                ++in_chain;
+            }
         }
-        for (int k = 0; k < d; ++k) {
-            const double e = loc_err[(size_t)j * d + k];
-            for (int u = 0; u < nu; ++u)
-                if (uniq[u] == e) td.dims[u][td.ndims[u]++] = k;
-        }
+        td.dstar = nchains;
+        td.nuniq = nu;
+        nu = nchains;
         ts->dstar_max = std::max(ts->dstar_max, nu);
         for (int u = 0; u < nu; ++u) ts->means_max = std::max(ts->means_max, (int)td.ndims[u]);
         ts->Tmax = std::max(ts->Tmax, (int)T[j]);
@@ -1172,16 +1227,24 @@ int bild_frames_executed(const bild_model *m, const bild_trajset *ts, int64_t n,
     return BILD_OK;
 }
 
+int bild_debug_frames_per_task(int32_t *d_buffer)
+{
+    g_frames_task.store(d_buffer);
+    return BILD_OK;
+}
+
 int bild_frames_run_read(const bild_model *m, int64_t *frames)
 {
     if (!m || !frames) return fail(BILD_ERR_INVALID, "NULL argument");
     *frames = 0;
     if (!m->d_frames) return BILD_OK;
-    unsigned long long v = 0;
+    unsigned long long v[kFrameCounters];
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(&v, m->d_frames, sizeof v, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(v, m->d_frames, sizeof v, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemset(m->d_frames, 0, sizeof v));
-    *frames = (int64_t)v;
+    unsigned long long tot = 0;
+    for (unsigned long long w : v) tot += w;
+    *frames = (int64_t)tot;
     return BILD_OK;
 }
 
@@ -1352,8 +1415,8 @@ int bild_flop_count(const bild_model *m, const bild_trajset *ts, int64_t n, cons
         const int tj = traj_id ? traj_id[r] : 0;
         if (tj < 0 || tj >= ts->n_traj) return fail(BILD_ERR_INVALID, "traj_id out of range");
         const TrajDesc &td = ts->descs[tj];
-        const double T = td.T, Tv = td.nvalid, ds = td.dstar;
-        can += (T - 1) * (4 * N * N * N * ds + 2 * N * N * d) + Tv * ((4 * N * N + 3 * N) * ds + 4 * N * d);
+        const double T = td.T, Tv = td.nvalid, ds = td.dstar, du = td.nuniq;
+        can += (T - 1) * (4 * N * N * N * du + 2 * N * N * d) + Tv * ((4 * N * N + 3 * N) * du + 4 * N * d);
         if (mode == kDense)
             exe += (T - 1) * (4 * nr * nr * nr * ds + 2 * nr * nr * d) + Tv * ((4 * nr * nr + 3 * nr) * ds + 4 * nr * d);
         else // elementwise predict (2 mul / entry) + update; basis changes at state switches not counted

@@ -5,7 +5,10 @@
 
 namespace bild {
 
-constexpr int kDMax = 3;      // spatial dimensions supported (reference default d = 3, models.py:222)
+constexpr int kDMax = 3;      // mean vectors ONE task carries (the reference default is d = 3, models.py:222)
+constexpr int kDStore = 8;    // spatial dimensions supported; with d > 3 a trajectory's dimensions are spread over
+constexpr int kChains = 8;    // several "covariance chains" of <= kDMax dimensions each (chains with equal localization
+                              // error repeat the covariance recursion: d = 4 costs two tasks per sample, d = 7 three)
 constexpr int kPadRows = 4;   // rows behind each trajectory on the device: the frame loops fetch that many frames ahead
 constexpr int kMaxWaves = 4;  // wavefronts per workgroup (fewer for long chains: LDS capacity)
 constexpr int kMaxNP = 32;    // largest padded chain length with a register-resident kernel (kernels.hip)
@@ -21,27 +24,28 @@ struct StateBlock {
     static constexpr int lam(int)     { return 0; }
     static constexpr int wq(int NP)   { return NP; }
     static constexpr int sig(int NP)  { return 2 * NP; }
-    static constexpr int G(int NP)    { return 3 * NP; }               // [kDMax][NP]
-    static constexpr int M0(int NP)   { return (3 + kDMax) * NP; }     // [kDMax][NP]
-    static constexpr int C0(int NP)   { return (3 + 2 * kDMax) * NP; } // [NP][NP]
-    static constexpr int size(int NP) { return (3 + 2 * kDMax) * NP + NP * NP; }
+    static constexpr int G(int NP)    { return 3 * NP; }                 // [kDStore][NP]
+    static constexpr int M0(int NP)   { return (3 + kDStore) * NP; }     // [kDStore][NP]
+    static constexpr int C0(int NP)   { return (3 + 2 * kDStore) * NP; } // [NP][NP]
+    static constexpr int size(int NP) { return (3 + 2 * kDStore) * NP + NP * NP; }
 };
 
 // Matrices that live in LDS for the whole kernel ("table"): stride padded by 2 doubles so the
 // same element of different matrices falls into different LDS banks.
 //   dense: B[s] at slot s, Sig[s] at slot S + s                     (2 S matrices)
-//   modal: R[s2][s] = Q[s2]^T Q[s] at slot s2 * S + s               (S*S matrices)
+//   modal: R[s2][s] = Q[s2]^T Q[s] at slot s2 * S + s               (S*S matrices), or, for many states,
+//          Q[s] at slot s and Q[s]^T at slot S + s                  (2 S matrices, basis change in two steps)
 constexpr int table_stride(int NP) { return NP * NP + 2; }
 
 struct TrajDesc {
     const double *x; // device, (T + kPadRows) x d: padding rows behind the data; every coordinate of a missing frame is NaN
     int32_t T;
-    int32_t dstar;           // number of distinct localization errors (pyx:145)
-    double s2[kDMax];        // their squares, ascending
-    int32_t ndims[kDMax];    // dims that use covariance chain e
-    int32_t dims[kDMax][kDMax];
+    int32_t dstar;           // number of covariance chains: distinct localization errors (pyx:145), split to <= kDMax dims
+    double s2[kChains];      // squared localization error of chain e (ascending; repeated where a chain was split)
+    int32_t ndims[kChains];  // dims that use covariance chain e (<= kDMax)
+    int32_t dims[kChains][kDMax];
     int32_t nvalid;          // frames with data
-    int32_t pad_;
+    int32_t nuniq;           // distinct localization errors (the reference's d*, pyx:145), <= dstar
     int64_t prefix_rec0;     // first record of this trajectory in the prefix table (records, see prefix_record_doubles)
     double xscale;           // largest |coordinate| of the data: absolute floor of the mean-vector comparison
 };
@@ -75,8 +79,9 @@ struct KParams {
     const double *prefix;   // prefix table to start from, null: every task starts at frame 0
     double *prefix_dump;    // non-null: this launch BUILDS the table (one task per (trajectory, e, s), K1 = 1)
     int32_t no_jump;        // with a prefix table: run every frame behind the first switch (no convergence jumps)
-    int32_t pad2_;
+    int32_t tab_factored;   // modal table = Q[s] at slot s, Q[s]^T at slot S + s (many states) instead of R[s2][s] at s2*S + s
     unsigned long long *frames_run; // non-null: tasks add the number of frames they ran themselves (bench accounting)
+    int32_t *frames_task;   // non-null (diagnostics): frames run by each task, indexed like `out`
 };
 
 // launch geometry for a padded chain length
@@ -94,6 +99,12 @@ struct Geometry {
 
 // doubles of LDS one group needs: image of X*[C|M], NP+kDMax columns of NP rows
 constexpr int group_image_doubles(int NP) { return (NP + kDMax) * NP; }
+// LDS layout of the vector kernels, in doubles: [matrix tables (tab_doubles)] [per state: lam | wq | sig (3 NP each)]
+// [per group: product image] [per group: the task's segment list, kSegLds (start, state) pairs]
+constexpr int kFrameCounters = 256; // words of the frames-run counter (KParams::frames_run), summed by the host
+constexpr int kSegLds = 16;
+constexpr int group_seg_doubles() { return kSegLds; } // 2 * kSegLds int32 (the list is cleaned in place)
+constexpr int state_header_doubles(int NP) { return 3 * NP; }
 
 // host-callable launchers implemented in kernels.hip
 int launch_logl(const Geometry &g, int mode, const KParams &p, int grid, size_t lds_bytes, void *stream);

@@ -200,12 +200,19 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
     // and a modal basis change walks its matrix row by row in a dependent loop -- from L2 that was
     // ~500 cycles per row, 10 us per switch (measured: +89 % kernel time at k = 20).
     for (int i = tid; i < p.tab_doubles; i += kThreads) smem[i] = p.tab[i];
+    // ... and so do the per-state vectors a state switch reloads (lam | wq | sig: the head of each state block)
+    constexpr int HDR = state_header_doubles(NP);
+    for (int i = tid; i < p.S * HDR; i += kThreads) smem[p.tab_doubles + i] = p.states[(size_t)(i / HDR) * StateBlock::size(NP) + i % HDR];
     __syncthreads();
     // per-group scratch: image of X*A, NP + kDMax columns of NP doubles; its first NP doubles
     // double as the all-gather buffer of the update
     if (grp >= GPW) return; // lanes beyond the last whole group (64 % G != 0) idle
-    const int lds_tab = p.tab_doubles;
+    const double *const lds_hdr = smem + p.tab_doubles;
+    const int lds_tab = p.tab_doubles + p.S * HDR;
     double *const scratch = smem + lds_tab + (size_t)(wv * GPW + grp) * group_image_doubles(NP);
+    // the task's segment list (K1 <= kSegLds): a switch then costs two LDS reads instead of two dependent L2 round trips
+    int32_t *const seg_lds = reinterpret_cast<int32_t *>(smem + lds_tab + (size_t)(kWaves * GPW) * group_image_doubles(NP)) +
+                             (size_t)(wv * GPW + grp) * (2 * kSegLds);
 
     int cidx[CPL];
     bool isC[CPL], hasImg[CPL];
@@ -280,9 +287,39 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
 
         const int32_t *__restrict__ sst = p.seg_start + r * K1;
         const int32_t *__restrict__ ssv = p.seg_state + r * K1;
+        // The segment list as given may hold boundaries that are no switches (a segment in the state of its predecessor),
+        // empty segments (equal starts) and segments beyond the trajectory.  Lists of up to kSegLds segments are copied
+        // to LDS and cleaned there, in place: what remains are the real switches inside the trajectory, strictly
+        // increasing -- so that a result depends on the expanded profile only, not on how it was encoded, and a switch
+        // costs two LDS reads instead of two dependent L2 round trips.  Longer lists are walked in global memory.
+        const bool seg_in_lds = K1 <= kSegLds;
+        int nseg = K1;
+        if (seg_in_lds) {
+            volatile int32_t *const sl = seg_lds;
+            for (int i = gl; i < K1; i += (BLK || ROW) ? 16 : G) {
+                sl[i] = sst[i];
+                sl[kSegLds + i] = ssv[i];
+            }
+            wave_lds_fence();
+            int cnt = 1, prev = sl[kSegLds];
+            for (int i = 1; i < K1; ++i) {
+                const int st0 = sl[i], sv = sl[kSegLds + i];
+                const int end = (i + 1 < K1) ? sl[i + 1] : INT_MAX;
+                if (st0 >= T) break;                    // starts are sorted: nothing behind this one is inside either
+                if (end <= st0 || sv == prev) continue; // empty, or not a change of state
+                sl[cnt] = st0;                          // cnt <= i: entries still to be read are not touched
+                sl[kSegLds + cnt] = sv;
+                prev = sv;
+                ++cnt;
+            }
+            nseg = cnt;
+            wave_lds_fence();
+        }
+        auto seg_start_of = [&](int i) { return seg_in_lds ? seg_lds[i] : sst[i]; };
+        auto seg_state_of = [&](int i) { return seg_in_lds ? seg_lds[kSegLds + i] : ssv[i]; };
         int seg = 0;
-        int s = ssv[0];
-        int next_start = (K1 > 1) ? sst[1] : INT_MAX;
+        int s = seg_state_of(0);
+        int next_start = (nseg > 1) ? seg_start_of(1) : INT_MAX;
 
         // ---- per-state registers -------------------------------------------------
         double wq[NP]; // measurement vector in the current basis
@@ -293,7 +330,7 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
         double sgd[NP];
         double wown = 0.0; // block layout: w_c of the own covariance column, 0 for the other lanes
         auto load_state = [&](int st) {
-            const double *__restrict__ sb = p.states + (size_t)st * SB;
+            const double *__restrict__ sb = lds_hdr + (size_t)st * HDR; // lam | wq | sig at the offsets of the state block
 #pragma unroll
             for (int i = 0; i < NP; ++i) wq[i] = sb[StateBlock::wq(NP) + i];
             if (BLK) wown = isC[0] ? sb[StateBlock::wq(NP) + cidx[0]] : 0.0;
@@ -449,11 +486,19 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
             if (t >= next_start) {
                 do {
                     ++seg;
-                    next_start = (seg + 1 < K1) ? sst[seg + 1] : INT_MAX;
-                } while (t >= next_start);
-                const int sn = ssv[seg];
+                    next_start = (seg + 1 < nseg) ? seg_start_of(seg + 1) : INT_MAX;
+                } while (t >= next_start); // (never loops on a cleaned list)
+                const int sn = seg_state_of(seg);
                 if (sn != s) {
-                    if (MODE == kModal) sandwich(const_cast<const double *>(smem) + (size_t)(sn * S + s) * MS, [] {});
+                    if (MODE == kModal) {
+                        // basis change: one matrix R[sn][s], or -- many states -- out of the old basis (Q[s]) and
+                        // into the new one (Q[sn]^T)
+                        const int steps = p.tab_factored ? 2 : 1;
+                        for (int st = 0; st < steps; ++st) {
+                            const int slot = p.tab_factored ? (st == 0 ? s : S + sn) : sn * S + s;
+                            sandwich(const_cast<const double *>(smem) + (size_t)slot * MS, [] {});
+                        }
+                    }
                     s = sn;
                     load_state(s);
                     t_sw = t;
@@ -638,7 +683,10 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
                 }
             }
         }
-        if (p.frames_run && gl == 0) atomicAdd(p.frames_run, (unsigned long long)nrun);
+        // bench accounting: one of kFrameCounters words per workgroup slot (a single word would serialise ten thousand
+        // atomics that all arrive at the end of a short launch)
+        if (p.frames_run && gl == 0) atomicAdd(p.frames_run + (blockIdx.x % kFrameCounters), (unsigned long long)nrun);
+        if (p.frames_task && gl == 0) p.frames_task[otask] = nrun;
 
         // ---- sum of the per-frame log-densities (pyx:88, 251-256) ---------------------
         double acc = 0.0;

@@ -59,7 +59,7 @@ class MultiStateRouse(MultiStateModel):
 
     N : int -- number of monomers
     D, k : float -- Rouse parameters
-    d : int -- spatial dimension (1..3)
+    d : int -- spatial dimension (1..8)
     looppositions : tuple -- per state ``None`` (no extra bond), ``(i, j[, rel_strength])`` or a
         list of such
     measurement : "end2end" or (N,) array

@@ -79,10 +79,11 @@ int bild_device_count(int *count);
  * states the propagator (B, G, Sig) and steady state (M0, C0) that the reference pulls
  * out of rouse.Model (._dynamics['B'|'G'|'Sig'], .steady_state()).
  *
- *   N  monomers, d spatial dimensions (1..3), S states
+ *   N  monomers, d spatial dimensions (1..8), S states
  *   B, Sig, C0 : S x N x N     G, M0 : S x N x d     w : N
  *
- * Envelope: d <= 3, S <= 255, and at most 128 modes left by the (exact) invariant-subspace
+ * Envelope: d <= 8 (a task carries up to three mean vectors; more dimensions with one localization error repeat
+ * the covariance recursion: d = 4..6 costs two tasks per sample, d = 7..8 three), S <= 255, and at most 128 modes left by the (exact) invariant-subspace
  * reduction -- N <= 256 monomers for the default end-to-end measurement, N <= 128 for an
  * arbitrary w; above 32 modes only the modal path exists.  Outside: BILD_ERR_UNSUPPORTED.
  *
@@ -242,6 +243,9 @@ int bild_frames_executed(const bild_model *m, const bild_trajset *ts, int64_t n,
 /* frames the tasks of all launches of this model ran themselves since the last call (counted on the device while
  * bild_kernel_timing is enabled; the rest came out of the prefix table); resets the counter; synchronises the device */
 int bild_frames_run_read(const bild_model *m, int64_t *frames);
+/* diagnostics: while d_buffer (device, one int32 per task = sample x localization-error chain) is set, every launch of
+ * the vector kernels records how many frames each task ran itself; NULL switches it off */
+int bild_debug_frames_per_task(int32_t *d_buffer);
 /* size of the table in bytes (0: none built) and the device time its construction took */
 int bild_prefix_info(const bild_trajset *ts, int64_t *bytes, double *build_ms);
 

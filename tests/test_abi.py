@@ -55,8 +55,9 @@ def test_model_argument_validation(built_lib):
     bad[0, 0, 0] = np.nan
     with pytest.raises(_lib.BildAmdError):
         _lib.ModelHandle(bad, a['G'], a['Sig'], a['M0'], a['C0'], w)
-    with pytest.raises(_lib.BildAmdError):        # d = 4 is outside the compiled envelope
-        _lib.ModelHandle(a['B'], np.zeros((2, 6, 4)), a['Sig'], np.zeros((2, 6, 4)), a['C0'], w)
+    assert _lib.ModelHandle(a['B'], np.zeros((2, 6, 4)), a['Sig'], np.zeros((2, 6, 4)), a['C0'], w).query(_lib.Q_D) == 4
+    with pytest.raises(_lib.BildAmdError):        # d = 9 is outside the compiled envelope (d <= 8)
+        _lib.ModelHandle(a['B'], np.zeros((2, 6, 9)), a['Sig'], np.zeros((2, 6, 9)), a['C0'], w)
 
 
 @pytest.mark.parametrize('N,loops,expect', [

@@ -927,3 +927,59 @@ def test_prefix_table_and_launch_order_do_not_change_results(built_lib, case):
     print(case, {k_: round(v, 3) for k_, v in shares.items()})
     assert 0.97 < shares['frame by frame'] <= 1.0          # frame 0 is not counted
     assert shares['table + jumps'] < shares['table'] < shares['frame by frame']
+
+
+@pytest.mark.parametrize('d,err', [(4, 0.1), (5, [0.1, 0.1, 0.1, 0.1, 0.3]), (6, [0.2, 0.1, 0.2, 0.1, 0.2, 0.1]), (8, 0.15),
+                                   (7, [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7])])
+@pytest.mark.parametrize('path', ['auto', 'dense'])
+def test_more_than_three_dimensions(built_lib, d, err, path):
+    """
+    The reference takes any d (bild/models.py:222).  A task carries up to three mean vectors; dimensions beyond that --
+    with one localization error or several -- run as further covariance chains of the same sample (d <= 8).
+    """
+    import bild_amd
+    from oracle import oracle
+    rng = np.random.default_rng(10 * d + len(path))
+    T, n, k = 160, 150, 3
+    model = bild_amd.MultiStateRouse(16, 1, 4, d=d, localization_error=err, path=path)
+    traj = model.trajectory_from_loopingprofile(H.random_profile(rng, T, 2, 40), missing_frames=0.06, rng=rng)
+    ss, thetas = H.candidate_profiles(rng, n, k, 2)
+    got = model.logL_st_batch(ss, thetas, traj)
+    want = oracle.logl_batch(model.arrays(), model.measurement, model.localization_error, traj[:], H.expand(ss, thetas, T))
+    assert np.max(np.abs(got - want)) < TOL
+    one = model.logL(H.ProfileView(H.expand(ss[:1], thetas[:1], T)[0]), traj)
+    assert abs(one - want[0]) < TOL
+
+
+@pytest.mark.parametrize('S', [6, 9, 24, 48])
+def test_many_states(built_lib, S):
+    """
+    The reference takes any number of states (bild/models.py:242-247).  Up to the point where all S*S basis changes fit
+    a quarter of LDS they are kept as pairs; beyond, as the 2 S factors Q[s], Q[s]^T and a switch changes basis in two
+    steps (S = 9 at 12 modes is already there).  Against the oracle, on both paths the model admits.
+    """
+    import bild_amd
+    from bild_amd import _lib
+    from oracle import oracle
+    rng = np.random.default_rng(S)
+    N, T, n, k = 12, 150, 200, 5
+    pairs = [(a, b) for span in range(2, N) for a in range(N - span) for b in [a + span]]        # 55 distinct bonds
+    loops = [None] + [pairs[i % len(pairs)] + (1.0 + 0.5 * (i // len(pairs)),) for i in range(S - 1)]
+    model = bild_amd.MultiStateRouse(N, 1, 3, d=2, looppositions=tuple(loops), localization_error=0.1)
+    assert model.nStates == S
+    traj = model.trajectory_from_loopingprofile(H.random_profile(rng, T, S, 30), missing_frames=0.05, rng=rng)
+    ss, thetas = H.candidate_profiles(rng, n, k, S)
+    want = oracle.logl_batch(model.arrays(), model.measurement, model.localization_error, traj[:], H.expand(ss, thetas, T))
+    for path in (['auto', 'dense'] if S <= 24 else ['auto']):
+        model.path = path
+        got = model.logL_st_batch(ss, thetas, traj)
+        assert np.max(np.abs(got - want)) < TOL, (S, path)
+        exact = _lib.logl_st(model.handle(), model.trajset(traj), ss, thetas, path=path, prefix=False)
+        assert np.max(np.abs(exact - want)) < TOL
+    if S == 48:
+        # the envelope: beyond ~50 states at 12 modes even the factors no longer fit LDS -- refused with a message
+        big = bild_amd.MultiStateRouse(N, 1, 3, d=2, looppositions=tuple([None] + [pairs[i % 55] + (1.0 + i,) for i in range(119)]),
+                                       localization_error=0.1)
+        with pytest.raises(_lib.BildAmdError) as info:
+            big.logL_st_batch(ss[:4], thetas[:4] % 2, traj)
+        assert info.value.code == _lib.ERR_UNSUPPORTED and 'too many states' in str(info.value)
