@@ -231,7 +231,7 @@ def main():
     # launch order of the resident candidates (a derived descriptor like the segments themselves: computed on the host
     # from the same (s, theta) batch, resident in HBM before the timed region; the api_seam figure includes computing it)
     order = _lib.schedule_segments(h, ts, seg_start, traj_id, path=args.path)
-    d_order = torch.from_numpy(order).to(dev)
+    d_order = None if np.array_equal(order, np.arange(len(order))) else torch.from_numpy(order).to(dev)   # identity: nothing to pass
     pad = max(sizes)
     d_out = torch.zeros(pad, dtype=torch.float64, device=dev)
     d_all = torch.empty(pad * world, dtype=torch.float64, device=dev)
@@ -240,7 +240,7 @@ def main():
         stream = torch.cuda.current_stream().cuda_stream
         _lib.logl_segments_device(h, ts, n, k + 1, d_start.data_ptr(), d_state.data_ptr(),
                                   d_tid.data_ptr() if d_tid is not None else 0, d_out.data_ptr(), stream=stream, path=path,
-                                  d_order=d_order.data_ptr() if prefix else 0, prefix=prefix)
+                                  d_order=d_order.data_ptr() if (prefix and d_order is not None) else 0, prefix=prefix)
         if world > 1:                                 # the one collective of an AMIS step
             if args.backend == 'nccl':
                 bdist.all_gather_logl(d_out, d_all)

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <climits>
+#include <emmintrin.h>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -751,6 +752,10 @@ bool schedule(const bild_model &m, const bild_trajset &ts, int64_t n, int K1, co
     int mode;
     if (n < 2 || K1 < 2 || n > INT_MAX || pick_mode(m, flags, &mode) || mode != kModal || m.wide || m.mid) return false;
     if ((flags & BILD_NO_PREFIX) || ts.prefix_state < 0 || getenv("BILD_NO_PREFIX") || getenv("BILD_NO_SCHEDULE")) return false;
+    // with convergence jumps a candidate runs ~50 frames per switch wherever its switches are: remaining length no
+    // longer says how long it takes, and sorting buys nothing (measured: 157 vs 160 us on the 10k batch,
+    // profiles/r02_prefix_jumps_ab.txt) -- not worth the host time
+    if (!(flags & BILD_NO_JUMP) && !getenv("BILD_NO_JUMP")) return false;
     Geometry geom{};
     if (!geometry_for(m.NPm[mode], mode, n * ts.dstar_max, ts.means_max, &geom)) return false;
     const int Tmax = ts.Tmax;
@@ -1298,10 +1303,12 @@ static int st_row(const double *s, const int64_t *th, int K1, int S, double Tm1,
         if (i + 1 < K1) {
             acc = acc + s[i];
             const double pos = acc * Tm1;
-            // floor(pos) for 0 <= pos < 2^31 is the truncating conversion (one SSE2 instruction, no libm call);
-            // anything else -- negative, NaN, or beyond any trajectory -- is sorted out below
-            const bool in_range = pos >= 0.0 && pos < 2147483646.0;
-            const int32_t idx = in_range ? (int32_t)((int64_t)pos + 1) : (pos >= 2147483646.0 ? INT_MAX : -1);
+            // floor(pos) for 0 <= pos < 2^31 is the truncating conversion (one SSE2 instruction, no libm call).  The
+            // intrinsic is defined for every input: NaN and out-of-range values give INT64_MIN, which the unsigned range
+            // test below rejects together with negative positions.
+            const int64_t fl = _mm_cvttsd_si64(_mm_set_sd(pos));
+            ok &= (uint64_t)fl < 2147483646ull;
+            const int32_t idx = (int32_t)fl + 1;
             ok &= idx >= prev;
             prev = idx;
             a[i + 1] = idx;
@@ -1311,7 +1318,7 @@ static int st_row(const double *s, const int64_t *th, int K1, int S, double Tm1,
     for (int i = 0; i < K1; ++i)
         if (th[i] < 0 || th[i] >= S)
             return fail(BILD_ERR_INVALID, "state %lld out of range at sample %lld", (long long)th[i], (long long)r);
-    return fail(BILD_ERR_INVALID, "interval lengths of sample %lld are not non-negative finite numbers", (long long)r);
+    return fail(BILD_ERR_INVALID, "interval lengths of sample %lld are not non-negative finite numbers (of a point on the simplex)", (long long)r);
 }
 
 int bild_segments_from_st(int64_t n, int K1, int n_states, const int32_t *T, int64_t T_stride, const double *ss,

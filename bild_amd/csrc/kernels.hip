@@ -812,6 +812,9 @@ int launch_geom(int mode, const KParams &p, int grid, size_t lds, hipStream_t st
 // automatically (1 = dense, 2 = modal, 3 = both).
 // The dense recursion is FMA-bound with one LDS operand feeding 2*CPL FMAs, so it wants several
 // columns per lane where the modal one wants a single column.
+#ifndef BILD_ROW_OCC
+#define BILD_ROW_OCC 3
+#endif
 #define BILD_GEOMETRIES(X)     \
     X(0, 4, 1, 7, 4, 3, 0, 3)     \
     X(1, 4, 2, 4, 4, 2, 0, 3)     \
@@ -820,7 +823,7 @@ int launch_geom(int mode, const KParams &p, int grid, size_t lds, hipStream_t st
     X(2, 8, 1, 11, 4, 3, 0, 3)    \
     X(19, 10, 1, 11, 4, 3, 0, 3)  \
     X(20, 10, 1, 12, 4, 3, 0, 3)  \
-    X(21, 10, 1, 16, 4, 3, 2, 2)  \
+    X(21, 10, 1, 16, 4, BILD_ROW_OCC, 2, 2)  \
     X(3, 10, 1, 13, 4, 3, 0, 3)   \
     X(4, 10, 2, 7, 4, 2, 0, 3)    \
     X(22, 12, 1, 16, 4, 2, 2, 2)  \

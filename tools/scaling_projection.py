@@ -1,0 +1,94 @@
+"""
+Strong-scaling projection from ONE GPU: per-rank kernel time of the shards an N-GPU run would hand to each rank, plus the
+latency of the step's one collective (measured here with RCCL at world size 1: the floor of the call, not of the wire).
+
+  configs[1]: 10 000 candidates x 1 trajectory, split into contiguous shards of 10000 / N
+  configs[2]: 256 trajectories x 1 000 candidates, whole trajectories per rank (256 / N each)
+
+    python tools/scaling_projection.py
+"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np, torch, torch.distributed as dist, helpers as H, bild_amd
+from bild_amd import _lib
+from bild_amd.profiles import segments_from_st
+
+T, k = 1000, 4
+dev = torch.device('cuda', 0)
+torch.cuda.set_device(0)
+os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29533')
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+
+
+def kernel_and_wall(model, trajs, ss, thetas, tid, reps=20):
+    h = model.handle()
+    ts = model.trajset(trajs if tid is not None else trajs[0])
+    a, b = segments_from_st(ss, thetas, T)
+    n = len(a)
+    da, db = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    dt_ = torch.from_numpy(tid).to(dev) if tid is not None else None
+    out = torch.empty(n, dtype=torch.float64, device=dev)
+    def go():
+        _lib.logl_segments_device(h, ts, n, k + 1, da.data_ptr(), db.data_ptr(), dt_.data_ptr() if dt_ is not None else 0,
+                                  out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    for _ in range(3):
+        go()
+    torch.cuda.synchronize()
+    _lib.kernel_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        go()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / reps
+    _lib.kernel_timing(False)
+    ms, c, _ = _lib.kernel_timing_read()
+    _lib.frames_run_read(h)
+    return ms / c * 1e-3, wall
+
+
+def allgather_latency(n_local, world_equiv, reps=200):
+    x = torch.zeros(n_local, dtype=torch.float64, device=dev)
+    y = torch.empty(n_local, dtype=torch.float64, device=dev)
+    for _ in range(10):
+        dist.all_gather_into_tensor(y, x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dist.all_gather_into_tensor(y, x)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+rng = np.random.default_rng(7)
+model = bild_amd.MultiStateRouse(20, 1., 5., d=3, localization_error=0.1)
+print("configs[1]: 10 000 candidates x 1 trajectory (T=1000, k=4), contiguous shards")
+traj = model.trajectory_from_loopingprofile(H.random_profile(rng, T, 2, 200), rng=rng)
+ss, thetas = H.candidate_profiles(rng, 10000, k, 2)
+base = None
+for N in (1, 2, 4, 8):
+    n = 10000 // N
+    kt, wall = kernel_and_wall(model, [traj], ss[:n], thetas[:n], None)
+    ag = allgather_latency(n, N)
+    step = max(kt, wall) + ag
+    base = base or step
+    print(f"  N={N}: {n:6d} candidates per rank: kernel {kt * 1e6:7.1f} us, launch-to-done {wall * 1e6:7.1f} us, all_gather(world 1, {n} doubles) "
+          f"{ag * 1e6:5.1f} us -> step {step * 1e6:7.1f} us = {10000 / step / 1e6:6.1f} M evals/s, x{base / step:4.2f} of N=1")
+
+print("configs[2]: 256 trajectories x 1 000 candidates (T=1000, k=4), whole trajectories per rank")
+trajs = [model.trajectory_from_loopingprofile(H.random_profile(rng, T, 2, 200), rng=rng) for _ in range(256)]
+ss, thetas = H.candidate_profiles(rng, 256000, k, 2)
+base = None
+for N in (1, 2, 4, 8):
+    nt = 256 // N
+    n = nt * 1000
+    tid = np.repeat(np.arange(nt), 1000).astype(np.int32)
+    kt, wall = kernel_and_wall(model, trajs[:nt], ss[:n], thetas[:n], tid, reps=8)
+    ag = allgather_latency(n, N)
+    step = max(kt, wall) + ag
+    base = base or step
+    print(f"  N={N}: {nt:3d} trajectories / {n:6d} candidates per rank: kernel {kt * 1e6:8.1f} us, launch-to-done {wall * 1e6:8.1f} us, "
+          f"all_gather(world 1, {n} doubles) {ag * 1e6:5.1f} us -> step {step * 1e6:8.1f} us = {256000 / step / 1e6:6.1f} M evals/s, x{base / step:4.2f} of N=1")
+print("(projection: every rank runs its shard concurrently; the collective on 8 GPUs over xGMI is latency-bound at these sizes "
+      "(80 KB / 2 MB gathered) -- RCCL ring all-gather of 8 x 256 KB is ~20-40 us in practice, against the world-1 call floor above)")
+dist.destroy_process_group()
