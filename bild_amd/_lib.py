@@ -44,6 +44,15 @@ _vp = ctypes.c_void_p
 _SIGNATURES = {
     'bild_abi_version': (ctypes.c_int, []),
     'bild_last_error': (ctypes.c_char_p, []),
+    'bild_set_last_error': (None, [ctypes.c_char_p]),
+    'bild_comm_library': (ctypes.c_int, [ctypes.c_char_p]),
+    'bild_comm_unique_id': (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
+    'bild_comm_create': (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_vp)]),
+    'bild_comm_allgather': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, _vp]),
+    'bild_comm_destroy': (ctypes.c_int, [_vp]),
+    'bild_device_alloc': (ctypes.c_int, [ctypes.c_int64, ctypes.POINTER(_vp)]),
+    'bild_device_free': (ctypes.c_int, [_vp]),
+    'bild_device_to_host': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, _vp]),
     'bild_device_count': (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
     'bild_model_create': (ctypes.c_int, [ctypes.c_int] * 3 + [_dp] * 6 + [ctypes.c_uint, ctypes.POINTER(_vp)]),
     'bild_model_destroy': (ctypes.c_int, [_vp]),
@@ -85,6 +94,8 @@ _SIGNATURES = {
 }
 
 _lib = None
+_torch_libdir = None     # set when the library was bound to the HIP runtime of an installed PyTorch
+_rccl_chosen = False
 
 
 def _share_hip_runtime_with_torch():
@@ -108,6 +119,8 @@ def _share_hip_runtime_with_torch():
     if os.path.exists(path):
         try:
             ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+            global _torch_libdir
+            _torch_libdir = os.path.dirname(path)
         except OSError:
             pass
 
@@ -346,6 +359,76 @@ def kernel_timing_read():
     name = ctypes.create_string_buffer(128)
     check(lib().bild_kernel_timing_read(ctypes.byref(ms), ctypes.byref(cnt), name, 128))
     return ms.value, cnt.value, name.value.decode()
+
+
+COMM_ID_BYTES = 128
+
+
+def _choose_rccl():
+    """
+    The RCCL that matches the HIP runtime in the process: when the library was bound to PyTorch's runtime (see
+    `_share_hip_runtime_with_torch`), PyTorch's own librccl.so beside it; else whatever the loader finds.
+    """
+    global _rccl_chosen
+    if _rccl_chosen:
+        return
+    _rccl_chosen = True
+    libdir = _torch_libdir
+    if libdir is None and 'torch' in __import__('sys').modules:
+        libdir = os.path.join(os.path.dirname(__import__('sys').modules['torch'].__file__), 'lib')
+    if libdir and os.path.exists(os.path.join(libdir, 'librccl.so')) and not os.environ.get('BILD_AMD_RCCL'):
+        lib().bild_comm_library(os.path.join(libdir, 'librccl.so').encode())
+
+
+def comm_unique_id():
+    """ 128 opaque bytes identifying a new communicator (rank 0 calls this and hands them to every rank) """
+    _choose_rccl()
+    buf = ctypes.create_string_buffer(COMM_ID_BYTES)
+    check(lib().bild_comm_unique_id(buf, COMM_ID_BYTES))
+    return buf.raw
+
+
+class CommHandle:
+    """ owns a ``bild_comm*`` (an RCCL communicator on the current device) """
+
+    def __init__(self, unique_id, world, rank):
+        assert len(unique_id) == COMM_ID_BYTES
+        _choose_rccl()
+        self.world, self.rank = int(world), int(rank)
+        self._h = _vp()
+        check(lib().bild_comm_create(unique_id, self.world, self.rank, ctypes.byref(self._h)))
+
+    def allgather(self, d_send, d_recv, n_per_rank, stream=0):
+        """ raw device pointers; asynchronous on `stream` """
+        check(lib().bild_comm_allgather(self._h, _vp(d_send), _vp(d_recv), int(n_per_rank), _vp(stream) if stream else None))
+
+    def __del__(self):
+        if getattr(self, '_h', None) and _lib is not None:
+            _lib.bild_comm_destroy(self._h)
+            self._h = None
+
+
+class DeviceBuffer:
+    """ a plain device allocation of `n` float64 (for host programs without a GPU framework) """
+
+    def __init__(self, n):
+        self.n = int(n)
+        self._p = _vp()
+        check(lib().bild_device_alloc(8 * self.n, ctypes.byref(self._p)))
+
+    @property
+    def ptr(self):
+        return self._p.value or 0
+
+    def to_host(self, n=None, stream=0):
+        out = np.empty(self.n if n is None else int(n), dtype=np.float64)
+        check(lib().bild_device_to_host(out.ctypes.data_as(_vp), self._p, 8 * out.size, _vp(stream) if stream else None))
+        return out
+
+    def __del__(self):
+        if getattr(self, '_p', None) and _lib is not None:
+            _lib.bild_device_free(self._p)
+            self._p = None
 
 
 class AmisCore:

@@ -904,6 +904,8 @@ int bild_abi_version(void) { return BILD_AMD_ABI_VERSION; }
 
 const char *bild_last_error(void) { return g_err.c_str(); }
 
+void bild_set_last_error(const char *msg) { g_err = msg ? msg : ""; }
+
 int bild_device_count(int *count)
 {
     if (!count) return fail(BILD_ERR_INVALID, "count is NULL");

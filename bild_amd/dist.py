@@ -67,6 +67,56 @@ def all_gather_logl_ragged(local, sizes, group=None):
     return torch.cat([buf[r * m:r * m + int(sizes[r])] for r in range(world)])
 
 
+class LibraryComm:
+    """
+    The step's collective through the library's own RCCL communicator (include/bild_amd.h, "several GPUs"): no PyTorch
+    in the multi-GPU path.  The 128-byte communicator id has to reach every rank by some channel of the host program;
+    two ready-made ones: a file on a shared file system (`from_file`) or an initialised ``torch.distributed`` group of
+    any backend (`from_torch`).  One process per GPU; the device must be current before the communicator is created.
+    """
+
+    def __init__(self, world, rank, unique_id):
+        from . import _lib
+        self.world, self.rank = int(world), int(rank)
+        self._comm = _lib.CommHandle(unique_id, world, rank)
+
+    @staticmethod
+    def new_id():
+        from . import _lib
+        return _lib.comm_unique_id()
+
+    @classmethod
+    def from_file(cls, path, world, rank, timeout=120.0):
+        import os
+        import time
+        from . import _lib
+        if rank == 0:
+            tmp = path + '.tmp'
+            with open(tmp, 'wb') as f:
+                f.write(_lib.comm_unique_id())
+            os.replace(tmp, path)          # appears atomically
+        t0 = time.time()
+        while not os.path.exists(path):
+            if time.time() - t0 > timeout:
+                raise TimeoutError(f"communicator id {path} did not appear")
+            time.sleep(0.01)
+        with open(path, 'rb') as f:
+            uid = f.read()
+        return cls(world, rank, uid)
+
+    @classmethod
+    def from_torch(cls, group=None):
+        import torch.distributed as dist
+        from . import _lib
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        box = [_lib.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        return cls(world, rank, box[0])
+
+    def allgather(self, d_send, d_recv, n_per_rank, stream=0):
+        self._comm.allgather(d_send, d_recv, n_per_rank, stream)
+
+
 class ShardedModel:
     """
     Multi-GPU likelihood for an AMIS loop that runs replicated on every rank (same seed, hence the
@@ -84,9 +134,10 @@ class ShardedModel:
     The process group is not part of the pickled state (a copy talks to the default group).
     """
 
-    def __init__(self, model, group=None, device=None, collective_at_world1=False):
+    def __init__(self, model, group=None, device=None, collective_at_world1=False, comm=None):
         self._model = model
         self._group = group
+        self._comm = comm      # a `LibraryComm`: shards, all-gather and the host copy go through the library alone
         self._collective_at_world1 = collective_at_world1   # tests: run the sharded path on a single rank too
         self._device = device  # where to stage the gathered vector: None -> cuda for nccl, cpu for gloo
         self._buffers = None   # (local, gathered) device tensors, grown on demand
@@ -105,6 +156,7 @@ class ShardedModel:
         state = dict(self.__dict__)
         state['_group'] = None
         state['_buffers'] = None
+        state['_comm'] = None
         return state
 
     def __setstate__(self, state):
@@ -124,7 +176,29 @@ class ShardedModel:
     def logL(self, profile, traj):
         return self._model.logL(profile, traj)
 
+    def _logL_st_batch_library(self, ss, thetas, traj):
+        from . import _lib
+        comm = self._comm
+        n = len(thetas)
+        bounds = [shard_bounds(n, comm.world, r) for r in range(comm.world)]
+        sizes = [b - a for a, b in bounds]
+        lo, hi = bounds[comm.rank]
+        m = max(sizes)
+        if self._buffers is None or self._buffers[0].n < m:
+            self._buffers = (_lib.DeviceBuffer(m), _lib.DeviceBuffer(m * comm.world))
+        local, gathered = self._buffers
+        if hi > lo:
+            self._model.logL_st_batch_to_device(ss[lo:hi], thetas[lo:hi], traj, local.ptr, stream=0)
+        comm.allgather(local.ptr, gathered.ptr, m, stream=0)          # default stream: ordered behind the kernel
+        host = gathered.to_host(m * comm.world)                       # the one device -> host copy of the step
+        self.host_copies += 1
+        return np.concatenate([host[r * m:r * m + sizes[r]] for r in range(comm.world)])
+
     def logL_st_batch(self, ss, thetas, traj):
+        if self._comm is not None:
+            if self._comm.world == 1 and not self._collective_at_world1:
+                return self._model.logL_st_batch(ss, thetas, traj)
+            return self._logL_st_batch_library(np.asarray(ss), np.asarray(thetas), traj)
         world, rank = self._world()
         if world == 1 and not (self._collective_at_world1 and self._initialised()):
             return self._model.logL_st_batch(ss, thetas, traj)

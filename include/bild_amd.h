@@ -69,6 +69,7 @@ typedef struct bild_trajset bild_trajset;
 
 int         bild_abi_version(void);
 const char *bild_last_error(void);
+void        bild_set_last_error(const char *msg); /* for the library's own translation units */
 
 /* Number of visible GPUs (0 without a device; never fails on a CPU-only host). */
 int bild_device_count(int *count);
@@ -248,6 +249,35 @@ int bild_frames_run_read(const bild_model *m, int64_t *frames);
 int bild_debug_frames_per_task(int32_t *d_buffer);
 /* size of the table in bytes (0: none built) and the device time its construction took */
 int bild_prefix_info(const bild_trajset *ts, int64_t *bytes, double *build_ms);
+
+/* ---------------------------------------------------------- several GPUs ------------
+ * One process per GPU.  The evaluations of a batch are independent, so ranks evaluate disjoint shards with no
+ * communication inside the likelihood; the ONE exchange of an AMIS step is an all-gather of the shards' results
+ * (every rank forms the importance weights from the full vector, bild/amis.py:843-845).  These calls put that
+ * collective behind the C ABI, on RCCL over xGMI, so that a multi-GPU host program needs nothing but this library:
+ *
+ *   rank 0:      bild_comm_unique_id(id)            -> 128 bytes, to be handed to every rank by ANY channel the host
+ *                                                      program has (file, socket, MPI, torch.distributed store ...)
+ *   every rank:  bild_comm_create(id, world, rank)  on the device that is current (one per rank)
+ *   per step:    bild_logl_st_to_device(... stream, d_local)   results of the rank's shard stay in HBM
+ *                bild_comm_allgather(comm, d_local, d_all, n_per_rank, stream)   same stream: ordered behind the kernel
+ *                one device-to-host copy of d_all
+ *
+ * Shards must be padded to a common length n_per_rank.  RCCL is located at run time (an RCCL already loaded into the
+ * process is used; else librccl.so.1; bild_comm_library(path) or BILD_AMD_RCCL name another one); without one the
+ * calls fail with BILD_ERR_UNSUPPORTED.  bild_amd/dist.py (LibraryComm, ShardedModel) is the Python binding. */
+#define BILD_COMM_ID_BYTES 128
+typedef struct bild_comm bild_comm;
+int bild_comm_library(const char *path);
+int bild_comm_unique_id(char *id, int id_len);
+int bild_comm_create(const char *id, int world, int rank, bild_comm **out);
+int bild_comm_allgather(bild_comm *c, const double *d_send, double *d_recv, int64_t n_per_rank, void *hip_stream);
+int bild_comm_destroy(bild_comm *c);
+/* device buffers for a host program that brings no GPU framework of its own (shard and gathered vector above);
+ * bild_device_to_host copies on `hip_stream` and waits for it */
+int bild_device_alloc(int64_t bytes, void **out);
+int bild_device_free(void *ptr);
+int bild_device_to_host(void *dst, const void *d_src, int64_t bytes, void *hip_stream);
 
 /* canonical floating-point operations of one batch,
  *   F = (T-1)(4 N^3 d* + 2 N^2 d) + Tv((4 N^2 + 3 N) d* + 4 N d)      

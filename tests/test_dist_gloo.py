@@ -245,3 +245,47 @@ def test_rccl_allgather_of_device_results(built_lib):
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY='0')
     r = subprocess.run([sys.executable, '-c', _RCCL_SCRIPT, ROOT], env=env, capture_output=True, text=True, timeout=300)
     assert 'RCCL_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+_LIBCOMM_SCRIPT = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import helpers as H, bild_amd
+from bild_amd import _lib, dist as bdist
+rng = np.random.default_rng(5)
+model = bild_amd.MultiStateRouse(20, 1, 5, d=3, localization_error=0.1)
+traj = model.trajectory_from_loopingprofile(H.random_profile(rng, 300, 2, 60), rng=rng)
+ss, thetas = H.candidate_profiles(rng, 321, 3, 2)
+host = model.logL_st_batch(ss, thetas, traj)
+comm = bdist.LibraryComm.from_file(sys.argv[2], 1, 0)            # rank 0 of 1: writes the id file and reads it back
+sm = bdist.ShardedModel(model, comm=comm, collective_at_world1=True)
+a = sm.logL_st_batch(ss, thetas, traj)
+b = sm.logL_st_batch(ss[:50], thetas[:50], traj)
+np.random.seed(4)
+sampler = bild_amd.FixedkSampler(traj, sm, k=3, N=64, max_fcomplete=0)
+before = sm.host_copies
+for _ in range(3):
+    sampler.step()
+np.random.seed(4)
+plain = bild_amd.FixedkSampler(traj, model, k=3, N=64, max_fcomplete=0)
+for _ in range(3):
+    plain.step()
+ok = (np.array_equal(a, host) and np.array_equal(b, host[:50]) and sm.host_copies - before == 3
+      and np.array_equal(np.array(sampler.evidences), np.array(plain.evidences)) and "torch" not in sys.modules)
+print("LIBCOMM_OK" if ok else "LIBCOMM_MISMATCH", "torch" in sys.modules)
+'''
+
+
+@pytest.mark.gpu
+def test_library_collective_without_pytorch(built_lib, tmp_path):
+    """
+    The multi-GPU step with nothing but the library: shard results stay in HBM (`bild_logl_st_to_device`), the all-gather
+    is the library's own RCCL call (`bild_comm_allgather`), one device-to-host copy per step -- and PyTorch is never
+    imported.  World size 1 (one GPU on the box); the id travels through a file, as it would between processes.
+    """
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, '-c', _LIBCOMM_SCRIPT, ROOT, str(tmp_path / 'comm.id')], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert 'LIBCOMM_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
