@@ -127,6 +127,19 @@ def cpu_baseline(seed, n, T, k, S, budget_s=15.0, procs=1):
                        f"(amis.py:735-739), {procs} process(es), BLAS pinned to 1 thread each"), outs[0]
 
 
+def _cpu_share():
+    """ host cores this process may really use: the affinity mask, capped by the cgroup CPU quota where there is one """
+    n = len(os.sched_getaffinity(0))
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            quota, period = f.read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -365,6 +378,12 @@ def main():
                 'value': n * reps / ndt, 'unit': 'evals/s', 'kernel': nname, 'kernel_ms': nkms,
                 'achieved': nexe / (nkms * 1e-3) / 1e12, 'frac': nexe / (nkms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
             }
+            # the same kernel code in its issue-bound regime, beside the default launch's figure
+            roofline['same_kernel_frame_by_frame'] = {'kernel_ms': nkms, 'achieved': nexe / (nkms * 1e-3) / 1e12,
+                                                      'frac': nexe / (nkms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                                                      'note': 'every frame of every candidate run (no prefix table): what the frame '
+                                                              'loop itself reaches of the fp64 peak; the default launch runs ~1/6 of '
+                                                              'the frames and is bound by dependent latencies (DESIGN.md section 4)'}
             a_out = d_out[:n].cpu().numpy().copy()
             step(args.path)
             torch.cuda.synchronize()
@@ -410,7 +429,7 @@ def main():
             result['parity_max_abs_diff_vs_cpu_baseline'] = float(np.max(np.abs(got - ref_out)))
             result['speedup_vs_cpu_baseline'] = value / base['value']
             if args.cpu_allcores:
-                cores = len(os.sched_getaffinity(0))
+                cores = _cpu_share()
                 allc, _ = cpu_baseline(rank, n, T, k, args.states, budget_s=10.0, procs=cores)
                 result['cpu_baseline_allcores'] = allc
                 result['speedup_vs_cpu_allcores'] = value / allc['value']

@@ -480,7 +480,11 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
             wave_lds_fence();
         };
 
-        int t_sw = INT_MIN / 2; // frame of the last change of state (drives the convergence checks below)
+#ifndef BILD_JUMP_FIRST
+#define BILD_JUMP_FIRST 24
+#endif
+        constexpr int kJumpFirst = BILD_JUMP_FIRST; // first comparison this many frames behind a switch
+        int t_check = 0; // frame index (frames < t_check are processed) at which the next convergence check is due
         // one frame t >= 1: state bookkeeping, predict (pyx:206-241), masked update (pyx:244-248)
         auto frame = [&](int t, const double (&xv)[CPL], double probe) {
             if (t >= next_start) {
@@ -501,7 +505,7 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
                     }
                     s = sn;
                     load_state(s);
-                    t_sw = t;
+                    t_check = t + kJumpFirst;
                 }
             }
             if (MODE == kModal) {
@@ -553,8 +557,9 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
         // frame.  With one, a task runs only where its filter differs from the switch-free filter of its current state:
         //  * it STARTS from the record in front of its first switch;
         //  * behind a switch the filter forgets where it came from at a geometric rate (a few tens of frames for a Rouse
-        //    chain).  Every kJumpEvery frames, from kJumpFirst frames behind the switch on, the task compares its whole
-        //    state [C | M] with the table's record of the same frame and state.  Equal states, same propagator and same
+        //    chain).  From kJumpFirst frames behind the switch on -- and then after as many frames as the measured deviation
+        //    still needs at the usual rate of decay -- the task compares its whole state [C | M] with the table's record of
+        //    the same frame and state.  Equal states, same propagator and same
         //    data give equal futures: once they agree to kJumpTol (relative to the largest entry of each column), the
         //    task takes the table's sums up to its next switch, continues from the record in front of that switch, and
         //    runs again from there.  No assumption about stationarity is made -- a task that never converges (long
@@ -564,13 +569,6 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
         // Rows of a wavefront are independent: each has its own frame counter and trajectory pointers.
         constexpr int NC = NP + kDMax;
         constexpr int REC = prefix_record_doubles(NP);
-#ifndef BILD_JUMP_FIRST
-#define BILD_JUMP_FIRST 24
-#endif
-#ifndef BILD_JUMP_EVERY
-#define BILD_JUMP_EVERY 8
-#endif
-        constexpr int kJumpFirst = BILD_JUMP_FIRST, kJumpEvery = BILD_JUMP_EVERY; // kJumpEvery: a power of two
         constexpr double kJumpTol = 1.1368683772161603e-13; // 2^-43
         const bool restore = !DUMP && p.prefix != nullptr;
         const bool jumping = restore && !p.no_jump;
@@ -599,6 +597,7 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
         if (restore) {
             // first frame this task may not take from the table; >= 1 (segment 0 owns frame 0)
             t = next_start < 1 ? 1 : (next_start < T ? next_start : T);
+            t_check = t + 8; // (the switch at t sets its own; lists too long to be cleaned may hold boundaries that switch nothing)
             const double *__restrict__ rec = record(t - 1);
             load_cols(rec);
 #pragma unroll
@@ -642,43 +641,57 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
             if constexpr (DUMP) dump(t);
             ++t;
             ++nrun;
-            if (jumping && t < T) {
-                const int dt = t - t_sw;
-                if (dt >= kJumpFirst && (dt & (kJumpEvery - 1)) == 0) {
-                    const double *__restrict__ rec = record(t - 1);
-                    bool same = true;
+            if (jumping && t == t_check && t < T) {
+                const double *__restrict__ rec = record(t - 1);
+                // per lane: largest deviation of the own column(s) from the table's, in units of the tolerance
+                double excess = 0.0;
+                bool same = true;
 #pragma unroll
-                    for (int q = 0; q < CPL; ++q) {
-                        if (!hasImg[q]) continue;
-                        double dev = 0.0, ref = isM[q] ? td->xscale : 0.0;
+                for (int q = 0; q < CPL; ++q) {
+                    if (!hasImg[q]) continue;
+                    double dev = 0.0, ref = isM[q] ? td->xscale : 0.0;
 #pragma unroll
-                        for (int i = 0; i < NP; i += 2) {
-                            const double2 r2 = *reinterpret_cast<const double2 *>(rec + cidx[q] * NP + i);
-                            dev = fmax(dev, fmax(fabs(col.v[q][i] - r2.x), fabs(col.v[q][i + 1] - r2.y)));
-                            ref = fmax(ref, fmax(fabs(r2.x), fabs(r2.y)));
-                        }
-                        same = same && (dev <= kJumpTol * ref); // a NaN anywhere never compares equal
+                    for (int i = 0; i < NP; i += 2) {
+                        const double2 r2 = *reinterpret_cast<const double2 *>(rec + cidx[q] * NP + i);
+                        dev = fmax(dev, fmax(fabs(col.v[q][i] - r2.x), fabs(col.v[q][i + 1] - r2.y)));
+                        ref = fmax(ref, fmax(fabs(r2.x), fabs(r2.y)));
                     }
-                    const unsigned long long agree = __ballot(same);
-                    if ((agree & group_mask) == group_mask) {
-                        const int t2 = next_start < T ? next_start : T;
-                        if (t2 > t) {
-                            const double *__restrict__ rec2 = record(t2 - 1);
+                    const double bar = kJumpTol * ref;
+                    same = same && (dev <= bar); // a NaN anywhere never compares equal
+                    excess = fmax(excess, dev > bar ? dev / fmax(bar, 1e-300) : 0.0);
+                }
+                const unsigned long long agree = __ballot(same);
+                if ((agree & group_mask) != group_mask) {
+                    // not yet: the deviation shrinks geometrically (the default Rouse model: 0.73 bits per frame), so the
+                    // next look comes after about the frames the worst column still needs at 1.3 frames per bit -- by the
+                    // lower edge of its bucket, i.e. rather too early than too late; a slower filter is simply asked again
+                    int wait = 4;
+                    if (__ballot(excess >= 0x1p4) & group_mask) wait = 8;
+                    if (__ballot(excess >= 0x1p8) & group_mask) wait = 12;
+                    if (__ballot(excess >= 0x1p16) & group_mask) wait = 24;
+                    if (__ballot(excess >= 0x1p24) & group_mask) wait = 32;
+                    if (__ballot(excess >= 0x1p32) & group_mask) wait = 44;
+                    if (__ballot(!(excess < 0x1p60)) & group_mask) wait = 64; // far off, or not a number
+                    t_check = t + wait;
+                } else {
+                    const int t2 = next_start < T ? next_start : T;
+                    t_check = t2 + 8; // (a switch at t2 sets its own)
+                    if (t2 > t) {
+                        const double *__restrict__ rec2 = record(t2 - 1);
 #pragma unroll
-                            for (int q = 0; q < CPL; ++q)
-                                if (isM[q]) accq[q] += rec2[NC * NP + (cidx[q] - NP)] - rec[NC * NP + (cidx[q] - NP)];
-                            int ex;
-                            P = frexp(P * (rec2[NC * NP + kDMax] / rec[NC * NP + kDMax]), &ex);
-                            E += ex + ((int)rec2[NC * NP + kDMax + 1] - (int)rec[NC * NP + kDMax + 1]);
-                            if (t2 < T) {
-                                load_cols(rec2);
+                        for (int q = 0; q < CPL; ++q)
+                            if (isM[q]) accq[q] += rec2[NC * NP + (cidx[q] - NP)] - rec[NC * NP + (cidx[q] - NP)];
+                        int ex;
+                        P = frexp(P * (rec2[NC * NP + kDMax] / rec[NC * NP + kDMax]), &ex);
+                        E += ex + ((int)rec2[NC * NP + kDMax + 1] - (int)rec[NC * NP + kDMax + 1]);
+                        if (t2 < T) {
+                            load_cols(rec2);
 #pragma unroll
-                                for (int q = 0; q < CPL; ++q) px[q] += (int64_t)xstep[q] * (t2 - t - 1);
-                                if (!ALLVALID) pprobe += (int64_t)d * (t2 - t - 1);
-                                fetch(xn, pn); // frame t2
-                            }
-                            t = t2;
+                            for (int q = 0; q < CPL; ++q) px[q] += (int64_t)xstep[q] * (t2 - t - 1);
+                            if (!ALLVALID) pprobe += (int64_t)d * (t2 - t - 1);
+                            fetch(xn, pn); // frame t2
                         }
+                        t = t2;
                     }
                 }
             }

@@ -217,7 +217,8 @@ int bild_logl_segments_device(const bild_model *m, const bild_trajset *ts, int64
  *
  * Behind a switch a Kalman filter forgets its starting point at a geometric rate: after a few tens of frames the
  * candidate's state [C | M] agrees with the table's record of the same frame and state to rounding.  The kernel checks
- * exactly that (whole state, every 8 frames from 24 frames behind the switch, relative tolerance 2^-43 per column) and,
+ * exactly that (whole state, first 24 frames behind the switch and then after as many frames as the measured deviation
+ * still needs at the usual rate of decay; relative tolerance 2^-43 per column) and,
  * once it holds, takes the table's sums up to the candidate's next switch and continues from the record in front of
  * it: equal state + same propagator + same data = same future.  Nothing is assumed about stationarity; a candidate
  * that does not converge runs every frame.  This changes results by ~1e-12 (differences of running sums, tolerance of
