@@ -243,7 +243,8 @@ def main():
     d_tid = torch.from_numpy(traj_id).to(dev) if traj_id is not None else None
     # launch order of the resident candidates (a derived descriptor like the segments themselves: computed on the host
     # from the same (s, theta) batch, resident in HBM before the timed region; the api_seam figure includes computing it)
-    order = _lib.schedule_segments(h, ts, seg_start, traj_id, path=args.path)
+    _lib.logl_segments(h, ts, seg_start, seg_state, traj_id, path=args.path)   # one evaluation of the batch: the set's tables exist now
+    order = _lib.schedule_segments(h, ts, seg_start, seg_state, traj_id, path=args.path)
     d_order = None if np.array_equal(order, np.arange(len(order))) else torch.from_numpy(order).to(dev)   # identity: nothing to pass
     pad = max(sizes)
     d_out = torch.zeros(pad, dtype=torch.float64, device=dev)

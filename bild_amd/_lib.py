@@ -67,7 +67,7 @@ _SIGNATURES = {
     'bild_logl_profiles': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int64, _ip, _ip, ctypes.c_uint, _dp]),
     'bild_logl_segments_device': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, _vp, _vp, _vp,
                                                  ctypes.c_uint, _vp, _vp]),
-    'bild_schedule_segments': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, _ip, _ip, ctypes.c_uint, _ip]),
+    'bild_schedule_segments': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, _ip, _ip, _ip, ctypes.c_uint, _ip]),
     'bild_logl_segments_device_ordered': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, _vp, _vp, _vp, _vp,
                                                          ctypes.c_uint, _vp, _vp]),
     'bild_frames_executed': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, _ip, _ip, _ip, ctypes.c_uint, _dp, _dp]),
@@ -302,13 +302,17 @@ def frames_run_read(model):
     return v.value
 
 
-def schedule_segments(model, ts, seg_start, traj_id=None, path='auto', prefix=True):
-    """ launch order for device-resident candidates (bild_schedule_segments): (n,) int32, order[slot] = sample """
-    seg_start = i32(seg_start)
+def schedule_segments(model, ts, seg_start, seg_state, traj_id=None, path='auto', prefix=True, jump=True):
+    """
+    launch order for device-resident candidates (bild_schedule_segments): (n,) int32, order[slot] = sample.  The work
+    estimate behind it uses the trajectory set's tables: evaluate something on the set once before asking.
+    """
+    seg_start, seg_state = i32(seg_start), i32(seg_state)
     n, K1 = seg_start.shape
     tid = None if traj_id is None else i32(traj_id)
     order = np.empty(n, dtype=np.int32)
-    check(lib().bild_schedule_segments(model._h, ts._h, n, K1, iptr(seg_start), iptr(tid), _flags(path, prefix=prefix), iptr(order)))
+    check(lib().bild_schedule_segments(model._h, ts._h, n, K1, iptr(seg_start), iptr(seg_state), iptr(tid),
+                                       _flags(path, prefix=prefix, jump=jump), iptr(order)))
     return order
 
 

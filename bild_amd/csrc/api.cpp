@@ -185,8 +185,20 @@ struct bild_trajset {
     mutable double *d_prefix = nullptr;
     mutable int64_t prefix_records = 0;
     mutable double prefix_build_ms = 0.0;
+    // transient table (common.h: TransEntry), built right behind the prefix table: 0 not tried, 1 built, -1 none
+    mutable std::atomic<int> trans_state{0};
+    mutable TransEntry *d_trans = nullptr;
+    mutable int64_t trans_entries = 0;
+    mutable double trans_build_ms = 0.0;
+    mutable std::atomic<int64_t> evals_seen{0}; // candidates evaluated on this set so far: the tables are built once they pay
+    mutable int trans_m_typ = 48;         // typical frames-to-convergence of the table's entries (90th percentile): the scheduler's yardstick
 };
 constexpr int kZeroPad = 8;
+constexpr unsigned kBuildTransients = 0x80000000u; // internal flag of launch_batch: fill the transient table
+// Candidates seen on a trajectory set before its tables are built.  Zero: at the first evaluation -- results then never depend
+// on what was evaluated before (a call that runs frame by frame and a later one that uses the tables would differ by ~1e-12).
+// Building costs about a millisecond per trajectory of 1000 frames (profiles/r02_transients.txt).
+constexpr int64_t kPrefixAfter = 0, kTransientsAfter = 0;
 
 namespace {
 
@@ -638,6 +650,88 @@ int ensure_prefix(const bild_model &m, const bild_trajset &ts, hipStream_t st)
 
 int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1, const int32_t *d_seg_start,
                  const int32_t *d_seg_state, const int32_t *d_traj_id, const int32_t *d_order, unsigned flags,
+                 hipStream_t st, double *d_out);
+
+// The transient table of a trajectory set (common.h: TransEntry), built once behind the prefix table: one ordinary
+// two-segment candidate per (trajectory, old state, new state, switch frame), evaluated by the likelihood kernel in its
+// table-building mode (it stops at the first successful convergence check and writes the entry instead of a result).
+int ensure_transients(const bild_model &m, const bild_trajset &ts, hipStream_t st)
+{
+    std::lock_guard<std::mutex> lk(ts.prefix_mu);
+    if (ts.trans_state != 0) return BILD_OK;
+    ts.trans_state = -1;
+    if (ts.prefix_state != 1 || getenv("BILD_NO_TRANSIENTS") || getenv("BILD_NO_JUMP") || m.S < 2) return BILD_OK;
+    const int S = m.S;
+    int64_t nb = 0;
+    for (const TrajDesc &td : ts.descs) nb += (int64_t)std::max(td.T - 1, 0) * S * (S - 1);
+    // the table is an optimisation: not for models with so many states that building it costs more than it can save
+    if (nb == 0 || nb > ((int64_t)4 << 20)) return BILD_OK;
+    const size_t bytes = (size_t)ts.trans_entries * sizeof(TransEntry);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes > free_b / 4) return BILD_OK;
+    std::vector<int32_t> host((size_t)5 * nb); // seg_start (2 per sample) | seg_state (2 per sample) | traj_id
+    int64_t r = 0;
+    for (int j = 0; j < ts.n_traj; ++j)
+        for (int s = 0; s < S; ++s)
+            for (int sn = 0; sn < S; ++sn) {
+                if (sn == s) continue;
+                for (int t = 1; t < ts.descs[j].T; ++t, ++r) {
+                    host[(size_t)2 * r] = 0;
+                    host[(size_t)2 * r + 1] = t;
+                    host[(size_t)2 * nb + 2 * r] = s;
+                    host[(size_t)2 * nb + 2 * r + 1] = sn;
+                    host[(size_t)4 * nb + r] = j;
+                }
+            }
+    int32_t *d_desc = nullptr;
+    double *d_sink = nullptr;
+    TransEntry *d_tab = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool ok = hipMalloc((void **)&d_desc, host.size() * sizeof(int32_t)) == hipSuccess &&
+              hipMalloc((void **)&d_sink, (size_t)nb * sizeof(double)) == hipSuccess &&
+              hipMalloc((void **)&d_tab, bytes) == hipSuccess && hipMemset(d_tab, 0, bytes) == hipSuccess &&
+              hipMemcpy(d_desc, host.data(), host.size() * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess &&
+              hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+    if (ok) {
+        ts.d_trans = d_tab; // launch_batch passes it on as the table to FILL (trans_state is still -1)
+        (void)hipEventRecord(e0, st);
+        ok = launch_batch(m, ts, nb, 2, d_desc, d_desc + 2 * nb, d_desc + 4 * nb, nullptr, BILD_PATH_MODAL | kBuildTransients, st,
+                          d_sink) == BILD_OK;
+        (void)hipEventRecord(e1, st);
+        ok = ok && hipStreamSynchronize(st) == hipSuccess;
+        float ms = 0.f;
+        if (ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) ts.trans_build_ms = ms;
+        ts.d_trans = nullptr;
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (d_desc) (void)hipFree(d_desc);
+    if (d_sink) (void)hipFree(d_sink);
+    if (ok) {
+        std::vector<TransEntry> all((size_t)ts.trans_entries);
+        ok = hipMemcpy(all.data(), d_tab, bytes, hipMemcpyDeviceToHost) == hipSuccess;
+        if (ok) {
+            std::vector<int32_t> ms;
+            for (const TransEntry &en : all)
+                if (en.m > 0) ms.push_back(en.m);
+            if (!ms.empty()) {
+                std::nth_element(ms.begin(), ms.begin() + ms.size() * 9 / 10, ms.end());
+                ts.trans_m_typ = ms[ms.size() * 9 / 10];
+            }
+        }
+    }
+    if (ok) {
+        ts.d_trans = d_tab;
+        ts.trans_state = 1;
+    } else {
+        if (d_tab) (void)hipFree(d_tab);
+        (void)hipGetLastError();
+    }
+    return BILD_OK;
+}
+
+int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1, const int32_t *d_seg_start,
+                 const int32_t *d_seg_state, const int32_t *d_traj_id, const int32_t *d_order, unsigned flags,
                  hipStream_t st, double *d_out)
 {
     int mode;
@@ -678,11 +772,21 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
     p.traj_id = d_traj_id;
     if (fam == kVector) {
         p.order = d_order;
-        if (mode == kModal && K1 > 0 && !(flags & BILD_NO_PREFIX)) {
-            if (ts.prefix_state == 0) ensure_prefix(m, ts, st);
-            if (ts.prefix_state == 1) p.prefix = ts.d_prefix;
-        }
         p.no_jump = (flags & BILD_NO_JUMP) || getenv("BILD_NO_JUMP") ? 1 : 0;
+        if (mode == kModal && K1 > 0 && !(flags & BILD_NO_PREFIX)) {
+            const int64_t seen = (flags & kBuildTransients) ? 0 : (ts.evals_seen += n);
+            static const char *after_env = getenv("BILD_TABLES_AFTER"); // experiments only: delay the tables
+            const int64_t prefix_after = after_env ? atoll(after_env) : kPrefixAfter;
+            const int64_t transients_after = after_env ? atoll(after_env) : kTransientsAfter;
+            if (ts.prefix_state == 0 && seen >= prefix_after) ensure_prefix(m, ts, st);
+            if (ts.prefix_state == 1) p.prefix = ts.d_prefix;
+            if (flags & kBuildTransients) {
+                p.trans_dump = ts.d_trans;
+            } else if (p.prefix && !p.no_jump) {
+                if (ts.trans_state == 0 && seen >= transients_after) ensure_transients(m, ts, st);
+                if (ts.trans_state == 1) p.trans = ts.d_trans;
+            }
+        }
         {
             std::lock_guard<std::mutex> lk(g_time_mu);
             if (g_time_on) p.frames_run = m.d_frames;
@@ -702,7 +806,6 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
     const int64_t tasks_per_block = fam == kWide ? 1 : fam != kVector ? 16 : (int64_t)geom.W * geom.tasks_per_wave();
     int64_t blocks = (p.ntasks + tasks_per_block - 1) / tasks_per_block;
     const int grid = (int)std::min<int64_t>(std::max<int64_t>(blocks, 1), 256 * 16);
-
     hipEvent_t e0 = nullptr, e1 = nullptr;
     bool timing;
     {
@@ -736,41 +839,84 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
     return BILD_OK;
 }
 
-// Launch order of a batch (vector kernels, modal path, prefix table in use).  A candidate starts at its first switch, so
-// candidates differ in length; the four (or so) tasks of a wavefront run in lockstep and finish with the longest.
-//  1. sort by remaining length, longest first: a wave's tasks then have neighbouring first switches (little is lost to
-//     the wave-wide start, their basis changes tend to coincide) and long work is dispatched first;
+// Launch order of a batch (vector kernels, modal path, tables in use).  Candidates differ in the number of frames they run
+// themselves; the four (or so) tasks of a wavefront are independent rows of one instruction stream, so the wave lives as long
+// as its busiest row.
+//  1. sort by the work a candidate will do, most first: a wave's rows then finish together, and long work is dispatched
+//     first.  The work is estimated from the candidate's switches and the transient table's frames-to-convergence (with
+//     BILD_NO_JUMP: the remaining length behind the first switch);
 //  2. when the whole grid is resident at once -- at most OCC workgroups per CU -- nothing is ever re-balanced at run time:
 //     the dispatcher deals workgroups to the 256 CUs round-robin (workgroups b, b + 256, b + 512 share a CU;
 //     measured: profiles/r02_placement.txt), so the sorted workgroups are dealt to CUs longest-processing-time-first
 //     with the CU's number of workgroups as capacity, and written out in that dealing order.
 // Purely a matter of speed: results do not depend on the order, and nothing relies on the dispatcher behaving so.
 // order[slot] = sample.  Returns false when the identity is as good (nothing written).
-bool schedule(const bild_model &m, const bild_trajset &ts, int64_t n, int K1, const int32_t *seg_start, const int32_t *traj_id,
-              unsigned flags, int32_t *order)
+bool schedule(const bild_model &m, const bild_trajset &ts, int64_t n, int K1, const int32_t *seg_start, const int32_t *seg_state,
+              const int32_t *traj_id, unsigned flags, int32_t *order, bool inside_a_call)
 {
     int mode;
     if (n < 2 || K1 < 2 || n > INT_MAX || pick_mode(m, flags, &mode) || mode != kModal || m.wide || m.mid) return false;
     if ((flags & BILD_NO_PREFIX) || ts.prefix_state < 0 || getenv("BILD_NO_PREFIX") || getenv("BILD_NO_SCHEDULE")) return false;
-    // with convergence jumps a candidate runs ~50 frames per switch wherever its switches are: remaining length no
-    // longer says how long it takes, and sorting buys nothing (measured: 157 vs 160 us on the 10k batch,
-    // profiles/r02_prefix_jumps_ab.txt) -- not worth the host time
-    if (!(flags & BILD_NO_JUMP) && !getenv("BILD_NO_JUMP")) return false;
+    const bool jumps = !(flags & BILD_NO_JUMP) && !getenv("BILD_NO_JUMP");
+    // with jumps but without a transient table every switch costs about the same wherever it is: nothing to sort by
+    if (jumps && ts.trans_state != 1) return false;
+    // Measured on the 10k batch (profiles/r02_transients.txt): with the tables the order is worth 22 us of kernel time and
+    // costs 62 us of host time -- inside a host-buffer call it does not pay; a caller with resident candidates computes
+    // it once (bild_schedule_segments) and reuses it.
+    if (jumps && inside_a_call) return false;
     Geometry geom{};
     if (!geometry_for(m.NPm[mode], mode, n * ts.dstar_max, ts.means_max, &geom)) return false;
-    const int Tmax = ts.Tmax;
-    // counting sort by remaining length, descending
-    std::vector<int32_t> count((size_t)Tmax + 2, 0), rem((size_t)n);
+    const int Tmax = ts.Tmax, m_typ = ts.trans_m_typ;
+    std::vector<int32_t> count((size_t)Tmax + 2, 0), work((size_t)n);
     for (int64_t r = 0; r < n; ++r) {
-        const int T = ts.descs[traj_id ? traj_id[r] : 0].T;
-        int t0 = seg_start[r * K1 + 1];
-        t0 = t0 < 1 ? 1 : (t0 > T ? T : t0);
-        rem[r] = T - t0;
-        ++count[Tmax - rem[r] + 1];
+        const TrajDesc &td = ts.descs[traj_id ? traj_id[r] : 0];
+        const int T = td.T;
+        const int32_t *a = seg_start + r * K1;
+        int w = 0;
+        if (!jumps) {
+            int t0 = a[1];
+            t0 = t0 < 1 ? 1 : (t0 > T ? T : t0);
+            w = T - t0;
+        } else {
+            // Frames the candidate will run itself, estimated from its switch frames alone: a switch whose segment is at
+            // least m_typ frames long (the table's typical frames-to-convergence) comes out of the transient table, unless a
+            // run is in progress, which then ends m_typ frames behind it; shorter segments chain into one run.  (Boundaries
+            // that switch nothing are rare and only blur the estimate.)
+            int run_from = -1;
+            for (int i = 1; i < K1; ++i) {
+                const int t = a[i];
+                if (t >= T) break;
+                const int nxt = (i + 1 < K1 && a[i + 1] < T) ? a[i + 1] : T;
+                if (nxt - t >= m_typ) {
+                    if (run_from >= 0) {
+                        w += t + m_typ - run_from;
+                        run_from = -1;
+                    }
+                } else if (run_from < 0) {
+                    run_from = t;
+                }
+            }
+            if (run_from >= 0) w += T - run_from;
+            w = w > Tmax ? Tmax : w;
+        }
+        work[r] = w;
+        ++count[Tmax - w + 1];
     }
     for (int i = 1; i <= Tmax + 1; ++i) count[i] += count[i - 1];
     std::vector<int32_t> sorted((size_t)n);
-    for (int64_t r = 0; r < n; ++r) sorted[count[Tmax - rem[r]]++] = (int32_t)r;
+    for (int64_t r = 0; r < n; ++r) sorted[count[Tmax - work[r]]++] = (int32_t)r;
+    if (jumps) {
+        // Most candidates of a batch run no frame at all, a few run hundreds, and the rows of a wave share one instruction
+        // stream: every event of a row (basis change, comparison, jump) is paid by the whole wave.  So the busy candidates
+        // are SPREAD: the heaviest go one per wave, the next heaviest fill the second rows, and so on -- a wave then holds
+        // one long row and light ones instead of four long rows whose events add up.
+        const int64_t rpw = geom.tasks_per_wave() % ts.dstar_max == 0 ? geom.tasks_per_wave() / ts.dstar_max : 1;
+        const int64_t nw = n / rpw, n_full = nw * rpw;
+        for (int64_t w = 0; w < nw; ++w)
+            for (int64_t j = 0; j < rpw; ++j) order[w * rpw + j] = sorted[j * nw + w];
+        for (int64_t i = n_full; i < n; ++i) order[i] = sorted[i]; // the lightest few: a last, partial wave
+        return true;
+    }
     const int64_t per_block = std::max<int64_t>(1, (int64_t)geom.W * geom.tasks_per_wave() / ts.dstar_max);
     const int64_t nb = (n + per_block - 1) / per_block;
     const int kCUs = 256;
@@ -793,7 +939,7 @@ bool schedule(const bild_model &m, const bild_trajset &ts, int64_t n, int K1, co
         at[(size_t)c + (size_t)kCUs * filled[c]] = b;
         ++filled[c];
         const int cap = c < extra ? rounds : rounds - 1;
-        if (filled[c] < cap) heap.push(Load(top.first + rem[sorted[b * per_block]] + 1, c));
+        if (filled[c] < cap) heap.push(Load(top.first + work[sorted[b * per_block]] + 1, c));
     }
     // only the last block of the sorted list can be short: it goes to the last position, so that blocks of samples and
     // workgroups stay aligned
@@ -860,7 +1006,7 @@ int run_staged(const bild_model *m, const bild_trajset *ts, int64_t n, int K1, c
     if ((rc = fill(h_start, h_state))) return rc;
     if (traj_id) std::memcpy(h_tid, traj_id, (size_t)n * sizeof(int32_t));
     clk.lap(0);
-    const bool ordered = schedule(*m, *ts, n, K1, h_start, traj_id, flags, h_order);
+    const bool ordered = schedule(*m, *ts, n, K1, h_start, h_state, traj_id, flags, h_order, true);
     clk.lap(1);
     const size_t in_bytes = (2 * nseg + (traj_id ? (size_t)n : 0) + (ordered ? (size_t)n : 0)) * sizeof(int32_t);
     int32_t *d_start = (int32_t *)m->ws_in.ptr, *d_state = d_start + nseg, *d_tid = traj_id ? d_state + nseg : nullptr;
@@ -1108,9 +1254,11 @@ int bild_trajset_create(const bild_model *m, int n_traj, const int32_t *T, const
         int64_t rec = 0;
         for (int j = 0; j < n_traj; ++j) {
             ts->descs[j].prefix_rec0 = rec;
+            ts->descs[j].trans0 = rec * m->S; // S entries (one per new state) for every prefix record
             rec += (int64_t)T[j] * m->S * ts->dstar_max;
         }
         ts->prefix_records = rec;
+        ts->trans_entries = rec * m->S;
     }
     he = hipMemcpy(ts->d_x, xd.data(), xd.size() * sizeof(double), hipMemcpyHostToDevice);
     if (he != hipSuccess) return cleanup(fail(BILD_ERR_HIP, "hipMemcpy failed: %s", hipGetErrorString(he)));
@@ -1128,6 +1276,7 @@ int bild_trajset_destroy(bild_trajset *ts)
     if (ts->d_x) (void)hipFree(ts->d_x);
     if (ts->d_descs) (void)hipFree(ts->d_descs);
     if (ts->d_prefix) (void)hipFree(ts->d_prefix);
+    if (ts->d_trans) (void)hipFree(ts->d_trans);
     delete ts;
     return BILD_OK;
 }
@@ -1182,7 +1331,7 @@ int bild_logl_segments_device(const bild_model *m, const bild_trajset *ts, int64
 }
 
 int bild_schedule_segments(const bild_model *m, const bild_trajset *ts, int64_t n, int K1, const int32_t *seg_start,
-                           const int32_t *traj_id, unsigned flags, int32_t *order)
+                           const int32_t *seg_state, const int32_t *traj_id, unsigned flags, int32_t *order)
 {
     if (!m || !ts || !order) return fail(BILD_ERR_INVALID, "NULL argument");
     if (ts->model != m) return fail(BILD_ERR_INVALID, "trajectory set belongs to a different model");
@@ -1191,7 +1340,7 @@ int bild_schedule_segments(const bild_model *m, const bild_trajset *ts, int64_t 
     if (traj_id)
         for (int64_t r = 0; r < n; ++r)
             if (traj_id[r] < 0 || traj_id[r] >= ts->n_traj) return fail(BILD_ERR_INVALID, "traj_id out of range");
-    if (!schedule(*m, *ts, n, K1, seg_start, traj_id, flags, order))
+    if (!schedule(*m, *ts, n, K1, seg_start, seg_state, traj_id, flags, order, false))
         for (int64_t r = 0; r < n; ++r) order[r] = (int32_t)r;
     return BILD_OK;
 }
@@ -1258,9 +1407,11 @@ int bild_frames_run_read(const bild_model *m, int64_t *frames)
 int bild_prefix_info(const bild_trajset *ts, int64_t *bytes, double *build_ms)
 {
     if (!ts) return fail(BILD_ERR_INVALID, "NULL handle");
-    const bool built = ts->prefix_state == 1;
-    if (bytes) *bytes = built ? ts->prefix_records * prefix_record_doubles(ts->model->NPm[kModal]) * (int64_t)sizeof(double) : 0;
-    if (build_ms) *build_ms = built ? ts->prefix_build_ms : 0.0;
+    const bool built = ts->prefix_state == 1, trans = ts->trans_state == 1;
+    if (bytes)
+        *bytes = (built ? ts->prefix_records * prefix_record_doubles(ts->model->NPm[kModal]) * (int64_t)sizeof(double) : 0) +
+                 (trans ? ts->trans_entries * (int64_t)sizeof(TransEntry) : 0);
+    if (build_ms) *build_ms = (built ? ts->prefix_build_ms : 0.0) + (trans ? ts->trans_build_ms : 0.0);
     return BILD_OK;
 }
 

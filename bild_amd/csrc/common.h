@@ -48,6 +48,18 @@ struct TrajDesc {
     int32_t nuniq;           // distinct localization errors (the reference's d*, pyx:145), <= dstar
     int64_t prefix_rec0;     // first record of this trajectory in the prefix table (records, see prefix_record_doubles)
     double xscale;           // largest |coordinate| of the data: absolute floor of the mean-vector comparison
+    int64_t trans0;          // first entry of this trajectory in the transient table
+};
+
+// Transient table (vector kernels, modal path, beside the prefix table): entry of (trajectory, chain e, old state s, new
+// state sn, frame t) at  trans0 + ((e * S + s) * S + sn) * T + t  -- a filter that sits on the switch-free filter of s in
+// front of frame t and switches to sn there needs m frames to converge onto the switch-free filter of sn, and over those
+// frames its log-likelihood exceeds that filter's by c.  m = T - t for a transient that runs to the end of the trajectory
+// without converging (usable by a last switch only); m <= 0: no entry.
+struct TransEntry {
+    double c;
+    int32_t m;
+    int32_t pad;
 };
 
 // Prefix table (vector kernels, modal path): the filter state after frame t of a task that has not switched yet
@@ -55,7 +67,8 @@ struct TrajDesc {
 // computed once per trajectory set by the likelihood kernel itself (one task per (trajectory, e, s) that stores its
 // state after every frame) and every candidate starts from the record in front of its first switch.
 // Record of frame t, in doubles: NP + kDMax columns of NP rows ([C | M] in the modal basis of s, column layout of
-// the kernels), then sum e^2/S per mean column (kDMax), P, E (mantissa / exponent of the running product of S), pad.
+// the kernels), then sum e^2/S per mean column (kDMax), P, E (mantissa / exponent of the running product of S), the running
+// log-likelihood L of the frames so far, the number of observed frames so far, pad.
 // Records of trajectory j: prefix_rec0 + ((e * S + s) * T + t).
 constexpr int prefix_record_doubles(int NP) { return (NP + kDMax) * NP + kDMax + 2 + 3; }
 
@@ -82,6 +95,8 @@ struct KParams {
     int32_t tab_factored;   // modal table = Q[s] at slot s, Q[s]^T at slot S + s (many states) instead of R[s2][s] at s2*S + s
     unsigned long long *frames_run; // non-null: tasks add the number of frames they ran themselves (bench accounting)
     int32_t *frames_task;   // non-null (diagnostics): frames run by each task, indexed like `out`
+    const TransEntry *trans; // transient table to take whole transients from, null: every transient is run
+    TransEntry *trans_dump;  // non-null: this launch BUILDS the transient table (one task per entry, K1 = 2)
 };
 
 // launch geometry for a padded chain length

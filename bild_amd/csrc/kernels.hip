@@ -167,7 +167,9 @@ __device__ __forceinline__ void matvec_to_lds(XPtr X, const Cols<NP, CPL> &in, d
 // LAY: 0 packed groups of G consecutive lanes; 1 a group is a 16-lane block of the f64 4x4x4 matrix instruction
 // (S as a block sum on the matrix pipe); 2 a group is a 16-lane row, cross-lane operands by DPP row broadcast
 // DUMP: this instantiation builds the prefix table (one per chain length is compiled, see launch_geom)
-template <int NP, int CPL, int G, int W, int OCC, int LAY, int MODE, int FLAVOR, bool DUMP = false>
+// JUMP: this instantiation carries the machinery that takes frames out of the tables (convergence checks, transient table);
+// the frame-by-frame instantiation stays lean (the jump code costs registers the frame loop then spills around)
+template <int NP, int CPL, int G, int W, int OCC, int LAY, int MODE, int FLAVOR, bool DUMP = false, bool JUMP = false>
 __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
 {
     constexpr bool HASG = FLAVOR == 0;
@@ -372,6 +374,7 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
         for (int q = 0; q < CPL; ++q) accq[q] = 0.0;
         double P = 1.0; // running product of S (mantissa), exponent in E
         int E = 0;
+        int nv = 0;     // observed frames behind these accumulators
 
         // ---- Kalman update (pyx:19-90) ---------------------------------------------
         auto update = [&](const double (&xv)[CPL]) {
@@ -401,6 +404,7 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
                 int ex;
                 P = frexp(P * Sv, &ex);
                 E += ex;
+                ++nv;
                 return;
             }
             // every lane publishes (no exec masking): mean / spare columns land behind the NP
@@ -443,6 +447,7 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
             int ex;
             P = frexp(P * Sv, &ex);
             E += ex;
+            ++nv;
         };
 
         // A <- X A for all columns, then C <- C X^T for the covariance part: two lane-local
@@ -552,27 +557,35 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
             if (ALLVALID || !isnan(probe)) update(xv);
         };
 
-        // ---- where to start, and which frames to run at all ------------------------------------------------------
-        // Without a prefix table: frame 0 is an update on the steady state without a predict (pyx:186-190), then every
-        // frame.  With one, a task runs only where its filter differs from the switch-free filter of its current state:
-        //  * it STARTS from the record in front of its first switch;
+        // ---- which frames to run at all ------------------------------------------------------------------------------
+        // Without tables: frame 0 is an update on the steady state without a predict (pyx:186-190), then every frame.
+        // With the tables of the trajectory set (common.h), a task runs only where its filter differs from the switch-free
+        // filter of its current state:
+        //  * the part in front of its first switch is a difference of the running log-likelihood L_s(t) of that filter;
         //  * behind a switch the filter forgets where it came from at a geometric rate (a few tens of frames for a Rouse
         //    chain).  From kJumpFirst frames behind the switch on -- and then after as many frames as the measured deviation
         //    still needs at the usual rate of decay -- the task compares its whole state [C | M] with the table's record of
-        //    the same frame and state.  Equal states, same propagator and same
-        //    data give equal futures: once they agree to kJumpTol (relative to the largest entry of each column), the
-        //    task takes the table's sums up to its next switch, continues from the record in front of that switch, and
-        //    runs again from there.  No assumption about stationarity is made -- a task that never converges (long
-        //    gaps, slow modes) simply runs every frame.  The sums picked up from the table are differences of running
-        //    totals; together with the tolerance that makes a result deviate from the frame-by-frame one by ~1e-12
-        //    (bound in DESIGN.md; BILD_NO_JUMP runs every frame behind the first switch, bit-identical to BILD_NO_PREFIX).
-        // Rows of a wavefront are independent: each has its own frame counter and trajectory pointers.
+        //    the same frame and state.  Equal states, same propagator and same data give equal futures: once they agree to
+        //    kJumpTol (relative to the largest entry of each column), the rest of the segment is again a difference of
+        //    L_s(t), and the task is back at a "synchronised point" in front of its next switch.  No stationarity is
+        //    assumed: a task that never converges (long gaps, slow modes) simply runs every frame;
+        //  * a transient that starts at a synchronised point depends on (trajectory, chain, frame, old state, new state)
+        //    only -- not on the candidate.  The TRANSIENT TABLE holds, for every such switch, how many frames m it takes to
+        //    converge and what it adds to the log-likelihood beyond the table's own sums.  A task whose next switch is at
+        //    least m frames away takes that entry and runs nothing.
+        // The pieces are sums of O(1e4) numbers taken apart and put together again: a result deviates from the
+        // frame-by-frame one by ~1e-11 (BILD_NO_JUMP runs every frame behind the first switch, bit-identical to
+        // BILD_NO_PREFIX).  Rows of a wavefront are independent: each has its own frame counter and trajectory pointers.
         constexpr int NC = NP + kDMax;
         constexpr int REC = prefix_record_doubles(NP);
+        constexpr int kRecP = NC * NP + kDMax, kRecE = kRecP + 1, kRecL = kRecP + 2, kRecNv = kRecP + 3;
         constexpr double kJumpTol = 1.1368683772161603e-13; // 2^-43
         const bool restore = !DUMP && p.prefix != nullptr;
-        const bool jumping = restore && !p.no_jump;
-        auto record = [&](int t) { return p.prefix + (td->prefix_rec0 + ((int64_t)e * S + s) * T + t) * REC; };
+        const bool jumping = JUMP && restore && !p.no_jump;
+        const bool building_transients = jumping && p.trans_dump != nullptr;
+        const bool use_transients = jumping && p.trans != nullptr && !building_transients;
+        auto record_of = [&](int st, int t) { return p.prefix + (td->prefix_rec0 + ((int64_t)e * S + st) * T + t) * REC; };
+        auto record = [&](int t) { return record_of(s, t); };
         auto load_cols = [&](const double *__restrict__ rec) {
 #pragma unroll
             for (int q = 0; q < CPL; ++q) {
@@ -590,30 +603,95 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
         unsigned long long group_mask;
         if (BLK) group_mask = 0x000F000F000F000Full << (4 * grp);
         else group_mask = (G == 64 ? ~0ull : ((1ull << G) - 1)) << (grp * G);
+        // log-likelihood of the frames behind the accumulators (pyx:88, 251-256), the same in every lane of the task
+        auto piece_value = [&]() {
+            double acc = 0.0;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) acc += isM[q] ? accq[q] : 0.0;
+            scratch[gl] = acc;
+            wave_lds_fence();
+            double tot = 0.0;
+#pragma unroll
+            for (int g2 = 0; g2 < G; ++g2) tot += scratch[g2];
+            wave_lds_fence();
+            const double logS = log_once(P) + (double)E * kLn2;
+            tot += (double)nd * (logS + (double)nv * kLog2Pi);
+            return -0.5 * tot;
+        };
+        auto reset_piece = [&]() {
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) accq[q] = 0.0;
+            P = 1.0;
+            E = 0;
+            nv = 0;
+        };
 
         int t = 1;
         int nrun = 0;
+        int s_loaded = s;   // state whose vectors (wq, L, sgd) are in registers
+        double extra = 0.0; // finished pieces: table differences, transient entries, own pieces that have ended
+        bool open_run = true; // the accumulators hold a piece that is not in `extra` yet
         double xc[CPL], xn[CPL], pc, pn;
-        if (restore) {
-            // first frame this task may not take from the table; >= 1 (segment 0 owns frame 0)
-            t = next_start < 1 ? 1 : (next_start < T ? next_start : T);
-            t_check = t + 8; // (the switch at t sets its own; lists too long to be cleaned may hold boundaries that switch nothing)
-            const double *__restrict__ rec = record(t - 1);
+        // start a run of own frames at frame t0 from the table's state in front of it (px / pprobe stand at frame 0)
+        int t_at = 0; // frame the trajectory pointers stand at
+        auto start_run = [&](int t0, bool cumulative) {
+            const double *__restrict__ rec = record(t0 - 1);
             load_cols(rec);
+            if (cumulative) { // accumulators continue the table's (BILD_NO_JUMP: bit-identical to the run from frame 0)
 #pragma unroll
-            for (int q = 0; q < CPL; ++q) accq[q] = isM[q] ? rec[NC * NP + (cidx[q] - NP)] : 0.0;
-            P = rec[NC * NP + kDMax];
-            E = (int)rec[NC * NP + kDMax + 1];
+                for (int q = 0; q < CPL; ++q) accq[q] = isM[q] ? rec[NC * NP + (cidx[q] - NP)] : 0.0;
+                P = rec[kRecP];
+                E = (int)rec[kRecE];
+                nv = (int)rec[kRecNv];
+            } else {
+                reset_piece();
+            }
+            if (s_loaded != s) {
+                load_state(s);
+                s_loaded = s;
+            }
 #pragma unroll
-            for (int q = 0; q < CPL; ++q) px[q] += (int64_t)xstep[q] * t;
-            if (!ALLVALID) pprobe += (int64_t)d * t;
-            fetch(xn, pn); // frame t (or the first padding row)
+            for (int q = 0; q < CPL; ++q) px[q] += (int64_t)xstep[q] * (t0 - t_at);
+            if (!ALLVALID) pprobe += (int64_t)d * (t0 - t_at);
+            fetch(xn, pn); // frame t0 (or the first padding row)
+            t_at = t0 + 1;
+            t_check = t0 + 8; // (a switch at t0 sets its own; lists too long to be cleaned may hold boundaries that switch nothing)
+            open_run = true;
+        };
+        // at a synchronised point in front of frame t (== next_start, or T): take whatever the tables hold
+        auto land = [&]() {
+            while (t < T && use_transients) {
+                const int sn = seg_state_of(seg + 1);
+                if (sn == s) break; // (uncleaned list) not a switch: run on
+                const int nn = (seg + 2 < nseg) ? seg_start_of(seg + 2) : INT_MAX;
+                const int t3 = nn < T ? nn : T;
+                const TransEntry en = p.trans[td->trans0 + (((int64_t)e * S + s) * S + sn) * T + t];
+                const double la = record_of(sn, t - 1)[kRecL], lb = record_of(sn, t3 - 1)[kRecL];
+                if (en.m <= 0 || t + en.m > t3) break; // the transient reaches into the next switch: run it
+                extra += en.c + (lb - la);
+                ++seg;
+                s = sn;
+                next_start = nn;
+                t = t3;
+            }
+        };
+        if (jumping) {
+            open_run = false;
+            t = next_start < 1 ? 1 : (next_start < T ? next_start : T); // first switch (>= 1: segment 0 owns frame 0), or T
+            if (!building_transients) {
+                extra = record(t - 1)[kRecL];
+                land();
+            }
+            if (t < T) start_run(t, false);
+        } else if (restore) {
+            t = next_start < 1 ? 1 : (next_start < T ? next_start : T);
+            start_run(t, true);
         } else {
             fetch(xc, pc); // frame 0
             fetch(xn, pn); // frame 1 (or the first padding row)
             if (ALLVALID || !isnan(pc)) update(xc);
         }
-        // this launch builds the table: the state after every frame goes to its record (tasks have K1 = 1, s is fixed)
+        // this launch builds the prefix table: the state after every frame goes to its record (tasks have K1 = 1, s is fixed)
         auto dump = [&](int tt) {
             double *__restrict__ rec = p.prefix_dump + (td->prefix_rec0 + ((int64_t)e * S + s) * T + tt) * REC;
 #pragma unroll
@@ -625,9 +703,12 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
                 }
                 if (isM[q]) rec[NC * NP + (cidx[q] - NP)] = accq[q];
             }
+            const double Lsofar = piece_value(); // running log-likelihood of the switch-free filter
             if (gl == 0) {
-                rec[NC * NP + kDMax] = P;
-                rec[NC * NP + kDMax + 1] = (double)E;
+                rec[kRecP] = P;
+                rec[kRecE] = (double)E;
+                rec[kRecL] = Lsofar;
+                rec[kRecNv] = (double)nv;
             }
         };
         if constexpr (DUMP) dump(0);
@@ -637,11 +718,16 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
             for (int q = 0; q < CPL; ++q) xc[q] = xn[q];
             pc = pn;
             fetch(xn, pn);
-            frame(t, xc, pc);
+            ++t_at;
+            {
+                const int s_before = s;
+                frame(t, xc, pc);
+                if (s != s_before) s_loaded = s;
+            }
             if constexpr (DUMP) dump(t);
             ++t;
             ++nrun;
-            if (jumping && t == t_check && t < T) {
+            if (JUMP && jumping && t == t_check && t < T) {
                 const double *__restrict__ rec = record(t - 1);
                 // per lane: largest deviation of the own column(s) from the table's, in units of the tolerance
                 double excess = 0.0;
@@ -674,47 +760,39 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
                     if (__ballot(!(excess < 0x1p60)) & group_mask) wait = 64; // far off, or not a number
                     t_check = t + wait;
                 } else {
+                    // converged at frame t: the own piece ends here
+                    extra += piece_value();
+                    open_run = false;
+                    if (building_transients) break;
                     const int t2 = next_start < T ? next_start : T;
-                    t_check = t2 + 8; // (a switch at t2 sets its own)
-                    if (t2 > t) {
-                        const double *__restrict__ rec2 = record(t2 - 1);
-#pragma unroll
-                        for (int q = 0; q < CPL; ++q)
-                            if (isM[q]) accq[q] += rec2[NC * NP + (cidx[q] - NP)] - rec[NC * NP + (cidx[q] - NP)];
-                        int ex;
-                        P = frexp(P * (rec2[NC * NP + kDMax] / rec[NC * NP + kDMax]), &ex);
-                        E += ex + ((int)rec2[NC * NP + kDMax + 1] - (int)rec[NC * NP + kDMax + 1]);
-                        if (t2 < T) {
-                            load_cols(rec2);
-#pragma unroll
-                            for (int q = 0; q < CPL; ++q) px[q] += (int64_t)xstep[q] * (t2 - t - 1);
-                            if (!ALLVALID) pprobe += (int64_t)d * (t2 - t - 1);
-                            fetch(xn, pn); // frame t2
-                        }
-                        t = t2;
-                    }
+                    extra += record(t2 - 1)[kRecL] - rec[kRecL];
+                    t = t2;
+                    land();
+                    if (t < T) start_run(t, false);
                 }
             }
+        }
+        if (open_run) extra += piece_value(); // a run that reached the end of the trajectory (all of it, without tables)
+        if (building_transients) {
+            // what this transient adds beyond the running sums of the new state's own filter over the same frames, and how
+            // many frames it took (frames < t are processed; it started at the switch, frame t0)
+            const int t0 = seg_start_of(1), s_old = seg_state_of(0), tb = t < T ? t : T;
+            const double c = extra - (record_of(s, tb - 1)[kRecL] - record_of(s, t0 - 1)[kRecL]);
+            if (gl == 0) {
+                TransEntry en;
+                en.c = c;
+                en.m = tb - t0;
+                en.pad = 0;
+                p.trans_dump[td->trans0 + (((int64_t)e * S + s_old) * S + s) * T + t0] = en;
+                p.out[otask] = 0.0;
+            }
+        } else if (gl == 0) {
+            p.out[otask] = extra;
         }
         // bench accounting: one of kFrameCounters words per workgroup slot (a single word would serialise ten thousand
         // atomics that all arrive at the end of a short launch)
         if (p.frames_run && gl == 0) atomicAdd(p.frames_run + (blockIdx.x % kFrameCounters), (unsigned long long)nrun);
         if (p.frames_task && gl == 0) p.frames_task[otask] = nrun;
-
-        // ---- sum of the per-frame log-densities (pyx:88, 251-256) ---------------------
-        double acc = 0.0;
-#pragma unroll
-        for (int q = 0; q < CPL; ++q) acc += isM[q] ? accq[q] : 0.0;
-        scratch[gl] = acc;
-        wave_lds_fence();
-        if (gl == 0) {
-            double tot = 0.0;
-#pragma unroll
-            for (int g2 = 0; g2 < G; ++g2) tot += scratch[g2];
-            const double logS = log_once(P) + (double)E * kLn2;
-            tot += (double)nd * (logS + (double)td->nvalid * kLog2Pi);
-            p.out[otask] = -0.5 * tot;
-        }
         wave_lds_fence();
     }
 }
@@ -779,6 +857,11 @@ int launch_geom(int mode, const KParams &p, int grid, size_t lds, hipStream_t st
         } else {
             return (int)hipErrorInvalidValue;
         }
+    }
+    if (mode == kModal && p.prefix && !p.no_jump) {
+        if (flavor == 0) return go(logl_kernel<NP, CPL, G, W, OCC, LAY, kModal, 0, false, true>);
+        if (flavor == 1) return go(logl_kernel<NP, CPL, G, W, OCC, LAY, kModal, 1, false, true>);
+        return go(logl_kernel<NP, CPL, G, W, OCC, LAY, kModal, 2, false, true>);
     }
     if (mode == kModal) {
         if (flavor == 0) return go(logl_kernel<NP, CPL, G, W, OCC, LAY, kModal, 0>);

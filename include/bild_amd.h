@@ -230,7 +230,8 @@ int bild_logl_segments_device(const bild_model *m, const bild_trajset *ts, int64
  * bild_logl_segments_device_ordered: order[slot] = index of the sample evaluated in slot `slot`; a permutation of
  * 0..n-1 (checked only with BILD_VALIDATE_DEVICE).  NULL = the order of the arrays. */
 int bild_schedule_segments(const bild_model *m, const bild_trajset *ts, int64_t n, int K1,
-                           const int32_t *seg_start, const int32_t *traj_id /* may be NULL */,
+                           const int32_t *seg_start, const int32_t *seg_state,
+                           const int32_t *traj_id /* may be NULL */,
                            unsigned flags, int32_t *order /* out, n */);
 int bild_logl_segments_device_ordered(const bild_model *m, const bild_trajset *ts, int64_t n, int K1,
                                       const int32_t *d_seg_start, const int32_t *d_seg_state,

@@ -64,3 +64,9 @@ def test_random_configuration(built_lib, seed):
     assert np.max(np.abs(got - want)) < TOL, (c['N'], c['d'], c['S'], T, c['nsw'], c['miss'], c['reduce'], c['path'])
     # expanded-profile entry point agrees bit for bit with the (s, theta) one
     assert np.array_equal(model.logL_batch(states, traj), got)
+    # every evaluation above went through the trajectory set's tables (prefix table, convergence jumps, transient table)
+    # where the kernel family has them; the frame-by-frame run of the same batch agrees to the jumps' tolerance
+    if c['path'] == 'modal':
+        exact = _lib.logl_st(model.handle(), model.trajset(traj), ss, thetas, path='modal', prefix=False)
+        assert np.max(np.abs(exact - want)) < TOL
+        assert np.max(np.abs(exact - got)) < 1e-9

@@ -886,7 +886,7 @@ def test_prefix_table_and_launch_order_do_not_change_results(built_lib, case):
     assert jump_dev < 1e-9
     # device entry: array order and scheduled order, with and without the table / the jumps
     dev = torch.device('cuda', 0)
-    order = _lib.schedule_segments(h, ts, seg_start, tid)
+    order = _lib.schedule_segments(h, ts, seg_start, seg_state, tid)
     assert np.array_equal(np.sort(order), np.arange(n))
     d = {name: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for name, v in
          dict(a=seg_start, b=seg_state, t=tid, o=order).items()}

@@ -23,13 +23,15 @@ h, ts = model.handle(), model.trajset(traj)
 dev = torch.device('cuda', 0)
 da, db = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
 out = torch.empty(n, dtype=torch.float64, device=dev)
-sched = _lib.schedule_segments(h, ts, a)
+_lib.logl_segments(h, ts, a, b)    # builds the tables
+sched = _lib.schedule_segments(h, ts, a, b, jump=False)
+sched_j = _lib.schedule_segments(h, ts, a, b)
 rem = T - np.clip(a[:, 1] if k > 0 else np.full(n, T), 1, T)
 plain_sort = np.argsort(-rem, kind='stable').astype(np.int32)
 ref = None
 for name, order, prefix, jump in (('frame 0, array order', None, False, False), ('prefix, array order', None, True, False),
                                   ('prefix, sorted', plain_sort, True, False), ('prefix, scheduler', sched, True, False),
-                                  ('prefix+jumps, array order', None, True, True), ('prefix+jumps, scheduler', sched, True, True)):
+                                  ('prefix+jumps, array order', None, True, True), ('prefix+jumps, scheduler', sched_j, True, True)):
     do = torch.from_numpy(order).to(dev) if order is not None else None
     def go():
         _lib.logl_segments_device(h, ts, n, k + 1, da.data_ptr(), db.data_ptr(), 0, out.data_ptr(),
