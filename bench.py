@@ -158,6 +158,7 @@ def main():
     ap.add_argument('--cpu-allcores', action='store_true', help='also time the reference kernel on every host core')
     ap.add_argument('--no-reduce', action='store_true', help='keep all N modes (skip the invariant-subspace reduction)')
     ap.add_argument('--no-secondary', action='store_true', help='skip the dense / canonical-path side measurements')
+    ap.add_argument('--no-seam', action='store_true', help='skip the api_seam measurement (profiling runs that want the headline launches alone)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help="collective backend; 'gloo' (log-likelihoods staged through host memory) rehearses the "
                          "multi-rank path on a box with fewer GPUs than ranks")
@@ -347,7 +348,7 @@ def main():
     }
 
     # ---- the seam: FixedkSampler.logL(ss, thetas), host arrays in, host array out ----------------------------
-    if traj_id is None:
+    if traj_id is None and not args.no_seam:
         model_for_sampler = bdist.ShardedModel(model) if (world > 1 and args.scaling == 'strong') else model
         sampler = bild_amd.FixedkSampler(trajs[0], model_for_sampler, k=k, N=len(ss), max_fcomplete=0)
         if world > 1 and args.scaling == 'strong':
