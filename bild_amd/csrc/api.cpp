@@ -784,7 +784,10 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
                 p.trans_dump = ts.d_trans;
             } else if (p.prefix && !p.no_jump) {
                 if (ts.trans_state == 0 && seen >= transients_after) ensure_transients(m, ts, st);
-                if (ts.trans_state == 1) p.trans = ts.d_trans;
+                if (ts.trans_state == 1) {
+                    p.trans = ts.d_trans;
+                    p.m_typ = ts.trans_m_typ;
+                }
             }
         }
         {

@@ -97,6 +97,7 @@ struct KParams {
     int32_t *frames_task;   // non-null (diagnostics): frames run by each task, indexed like `out`
     const TransEntry *trans; // transient table to take whole transients from, null: every transient is run
     TransEntry *trans_dump;  // non-null: this launch BUILDS the transient table (one task per entry, K1 = 2)
+    int32_t m_typ;           // with `trans`: typical frames-to-convergence of a transient (wave priority by expected work)
 };
 
 // launch geometry for a padded chain length

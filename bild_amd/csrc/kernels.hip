@@ -43,6 +43,13 @@
 
 #include "common.h"
 
+// expected frames of a wave's busiest row from which it asks for issue priority 1 / 2 / 3 (logl_kernel, "wave priority")
+#ifndef BILD_PRIO_T1
+#define BILD_PRIO_T1 100
+#define BILD_PRIO_T2 130
+#define BILD_PRIO_T3 160
+#endif
+
 namespace bild {
 namespace {
 
@@ -235,6 +242,11 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
         const int e = (int)(task - slot * p.dstar_max);
         const int64_t r = p.order ? p.order[slot] : slot; // launch order is a scheduling matter only
         const int64_t otask = r * p.dstar_max + e;
+#ifdef BILD_TASK_CLOCK
+        const unsigned long long clock_begin = wall_clock64(); // diagnostics build only: tools/task_clock.py
+        unsigned long long clock_events = 0;                   // (== 2: ticks inside comparisons / jumps, and how many)
+        int n_events = 0;
+#endif
         const int tj = p.traj_id ? p.traj_id[r] : 0;
         const TrajDesc *__restrict__ td = p.trajs + tj;
         if (e >= td->dstar) {
@@ -319,6 +331,32 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
         }
         auto seg_start_of = [&](int i) { return seg_in_lds ? seg_lds[i] : sst[i]; };
         auto seg_state_of = [&](int i) { return seg_in_lds ? seg_lds[kSegLds + i] : ssv[i]; };
+        // Wave priority.  The launch ends when its longest chain of short segments has been run, frame by frame, by ONE
+        // row -- on a SIMD shared with two other waves that mostly have slack.  A wave that expects a long run asks the
+        // issue arbiter for priority (frames to run estimated from the switch frames, as the host scheduler does):
+        // 136 -> 119 us for the 10k batch in array order, 116 -> 114 us in the scheduler's order
+        // (profiles/r02_wave_priority.txt).  A matter of speed only.
+        if (JUMP && seg_in_lds && p.trans != nullptr) {
+            int w = 0, run_from = -1;
+            const int mt = p.m_typ;
+            for (int i = 1; i < nseg; ++i) {
+                const int t1 = seg_lds[i];
+                const int nxt = (i + 1 < nseg) ? seg_lds[i + 1] : T;
+                if (nxt - t1 >= mt) {
+                    if (run_from >= 0) {
+                        w += t1 + mt - run_from;
+                        run_from = -1;
+                    }
+                } else if (run_from < 0) {
+                    run_from = t1;
+                }
+            }
+            if (run_from >= 0) w += T - run_from;
+            if (__ballot(w >= BILD_PRIO_T3)) __builtin_amdgcn_s_setprio(3);
+            else if (__ballot(w >= BILD_PRIO_T2)) __builtin_amdgcn_s_setprio(2);
+            else if (__ballot(w >= BILD_PRIO_T1)) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
         int seg = 0;
         int s = seg_state_of(0);
         int next_start = (nseg > 1) ? seg_start_of(1) : INT_MAX;
@@ -728,6 +766,9 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
             ++t;
             ++nrun;
             if (JUMP && jumping && t == t_check && t < T) {
+#if defined(BILD_TASK_CLOCK) && BILD_TASK_CLOCK == 2
+                const unsigned long long ev0 = wall_clock64();
+#endif
                 const double *__restrict__ rec = record(t - 1);
                 // per lane: largest deviation of the own column(s) from the table's, in units of the tolerance
                 double excess = 0.0;
@@ -770,6 +811,10 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
                     land();
                     if (t < T) start_run(t, false);
                 }
+#if defined(BILD_TASK_CLOCK) && BILD_TASK_CLOCK == 2
+                clock_events += wall_clock64() - ev0;
+                ++n_events;
+#endif
             }
         }
         if (open_run) extra += piece_value(); // a run that reached the end of the trajectory (all of it, without tables)
@@ -792,7 +837,13 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
         // bench accounting: one of kFrameCounters words per workgroup slot (a single word would serialise ten thousand
         // atomics that all arrive at the end of a short launch)
         if (p.frames_run && gl == 0) atomicAdd(p.frames_run + (blockIdx.x % kFrameCounters), (unsigned long long)nrun);
+#ifdef BILD_TASK_CLOCK
+        if (p.frames_task && gl == 0)
+            p.frames_task[otask] = BILD_TASK_CLOCK == 2 ? (int32_t)(((clock_events & 0xffffull) << 16) | (unsigned)n_events)
+                                                        : (int32_t)(((clock_begin & 0xffffull) << 16) | (wall_clock64() & 0xffffull));
+#else
         if (p.frames_task && gl == 0) p.frames_task[otask] = nrun;
+#endif
         wave_lds_fence();
     }
 }
