@@ -191,10 +191,22 @@ struct bild_trajset {
     mutable int64_t trans_entries = 0;
     mutable double trans_build_ms = 0.0;
     mutable std::atomic<int64_t> evals_seen{0}; // candidates evaluated on this set so far: the tables are built once they pay
+    mutable std::atomic<int> trans2_state{0}; // pair table (two switches as one transient): 0 not tried, 1 built, -1 not available
+    mutable TransEntry *d_trans2 = nullptr;
+    mutable int64_t trans2_entries = 0;
+    mutable double trans2_build_ms = 0.0;
+    mutable int gap_max = 0;              // gaps 1 .. gap_max - 1 are in the pair table
+    mutable int trans_m_max = 0;          // longest converged transient of the single table
     mutable int trans_m_typ = 48;         // typical frames-to-convergence of the table's entries (90th percentile): the scheduler's yardstick
 };
 constexpr int kZeroPad = 8;
-constexpr unsigned kBuildTransients = 0x80000000u; // internal flag of launch_batch: fill the transient table
+// set by ensure_transients / ensure_pairs around their own launch: this launch FILLS a table (1: transients, 2: pairs) --
+// a thread-local marker, not a bit of `flags`, so that no caller's flags can ever ask for it
+thread_local int tl_building = 0;
+struct BuildingScope {
+    explicit BuildingScope(int what) { tl_building = what; }
+    ~BuildingScope() { tl_building = 0; }
+}; // internal flag of launch_batch: fill the transient table
 // Candidates seen on a trajectory set before its tables are built.  Zero: at the first evaluation -- results then never depend
 // on what was evaluated before (a call that runs frame by frame and a later one that uses the tables would differ by ~1e-12).
 // Building costs about a millisecond per trajectory of 1000 frames (profiles/r02_transients.txt).
@@ -695,8 +707,10 @@ int ensure_transients(const bild_model &m, const bild_trajset &ts, hipStream_t s
     if (ok) {
         ts.d_trans = d_tab; // launch_batch passes it on as the table to FILL (trans_state is still -1)
         (void)hipEventRecord(e0, st);
-        ok = launch_batch(m, ts, nb, 2, d_desc, d_desc + 2 * nb, d_desc + 4 * nb, nullptr, BILD_PATH_MODAL | kBuildTransients, st,
-                          d_sink) == BILD_OK;
+        {
+            BuildingScope scope(1);
+            ok = launch_batch(m, ts, nb, 2, d_desc, d_desc + 2 * nb, d_desc + 4 * nb, nullptr, BILD_PATH_MODAL, st, d_sink) == BILD_OK;
+        }
         (void)hipEventRecord(e1, st);
         ok = ok && hipStreamSynchronize(st) == hipSuccess;
         float ms = 0.f;
@@ -714,6 +728,19 @@ int ensure_transients(const bild_model &m, const bild_trajset &ts, hipStream_t s
             std::vector<int32_t> ms;
             for (const TransEntry &en : all)
                 if (en.m > 0) ms.push_back(en.m);
+            // longest transient that converged (entries that ran into the trajectory's end say nothing about the filter)
+            {
+                int64_t i0 = 0;
+                for (const TrajDesc &td : ts.descs) {
+                    const int64_t cnt = (int64_t)td.T * S * S * ts.dstar_max;
+                    for (int64_t i = 0; i < cnt; ++i) {
+                        const TransEntry &en = all[(size_t)(i0 + i)];
+                        const int t = (int)(i % td.T);
+                        if (en.m > 0 && t + en.m < td.T) ts.trans_m_max = std::max(ts.trans_m_max, (int)en.m);
+                    }
+                    i0 += cnt;
+                }
+            }
             if (!ms.empty()) {
                 std::nth_element(ms.begin(), ms.begin() + ms.size() * 9 / 10, ms.end());
                 ts.trans_m_typ = ms[ms.size() * 9 / 10];
@@ -723,6 +750,85 @@ int ensure_transients(const bild_model &m, const bild_trajset &ts, hipStream_t s
     if (ok) {
         ts.d_trans = d_tab;
         ts.trans_state = 1;
+    } else {
+        if (d_tab) (void)hipFree(d_tab);
+        (void)hipGetLastError();
+    }
+    return BILD_OK;
+}
+
+// The pair table (common.h): two switches closer together than the first one's transient, as one entry.  Built like the
+// transient table, by the kernel itself, from candidates with two switches: one per (trajectory, s -> sn -> sm, frame, gap).
+// Only for trajectory sets where it can pay: the build is a launch of (T - 1) (gap_max - 1) S (S-1)^2 short tasks per
+// trajectory, worth it for sets that see batch after batch of candidates (one trajectory, ten thousand candidates per AMIS
+// step), not for hundreds of trajectories with a few candidates each -- decided by the size of the build alone, so that a
+// result never depends on what was evaluated before.
+int ensure_pairs(const bild_model &m, const bild_trajset &ts, hipStream_t st)
+{
+    std::lock_guard<std::mutex> lk(ts.prefix_mu);
+    if (ts.trans2_state != 0) return BILD_OK;
+    ts.trans2_state = -1;
+    if (ts.trans_state != 1 || getenv("BILD_NO_PAIRS") || m.S < 2) return BILD_OK;
+    const int S = m.S, G = std::min(64, ts.trans_m_max);
+    if (G < 2) return BILD_OK;
+    int64_t nb = 0;
+    for (const TrajDesc &td : ts.descs) nb += (int64_t)std::max(td.T - 1, 0) * (G - 1) * S * (S - 1) * (S - 1);
+    if (nb == 0 || nb > ((int64_t)2 << 20)) return BILD_OK;
+    const int64_t entries = ts.trans_entries * S * G;
+    const size_t bytes = (size_t)entries * sizeof(TransEntry);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes > free_b / 4) return BILD_OK;
+    std::vector<int32_t> host((size_t)7 * nb); // seg_start (3 per sample) | seg_state (3 per sample) | traj_id
+    int64_t r = 0;
+    for (int j = 0; j < ts.n_traj; ++j)
+        for (int s = 0; s < S; ++s)
+            for (int sn = 0; sn < S; ++sn) {
+                if (sn == s) continue;
+                for (int sm = 0; sm < S; ++sm) {
+                    if (sm == sn) continue;
+                    for (int t = 1; t < ts.descs[j].T; ++t)
+                        for (int g = 1; g < G; ++g, ++r) {
+                            host[(size_t)3 * r] = 0;
+                            host[(size_t)3 * r + 1] = t;
+                            host[(size_t)3 * r + 2] = t + g; // beyond the end: the kernel voids the entry
+                            host[(size_t)3 * nb + 3 * r] = s;
+                            host[(size_t)3 * nb + 3 * r + 1] = sn;
+                            host[(size_t)3 * nb + 3 * r + 2] = sm;
+                            host[(size_t)6 * nb + r] = j;
+                        }
+                }
+            }
+    int32_t *d_desc = nullptr;
+    double *d_sink = nullptr;
+    TransEntry *d_tab = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool ok = hipMalloc((void **)&d_desc, host.size() * sizeof(int32_t)) == hipSuccess &&
+              hipMalloc((void **)&d_sink, (size_t)nb * sizeof(double)) == hipSuccess &&
+              hipMalloc((void **)&d_tab, bytes) == hipSuccess && hipMemset(d_tab, 0, bytes) == hipSuccess &&
+              hipMemcpy(d_desc, host.data(), host.size() * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess &&
+              hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+    if (ok) {
+        ts.d_trans2 = d_tab; // launch_batch passes it on as the table to FILL (trans2_state is still -1)
+        ts.gap_max = G;
+        (void)hipEventRecord(e0, st);
+        {
+            BuildingScope scope(2);
+            ok = launch_batch(m, ts, nb, 3, d_desc, d_desc + 3 * nb, d_desc + 6 * nb, nullptr, BILD_PATH_MODAL, st, d_sink) == BILD_OK;
+        }
+        (void)hipEventRecord(e1, st);
+        ok = ok && hipStreamSynchronize(st) == hipSuccess;
+        float ms = 0.f;
+        if (ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) ts.trans2_build_ms = ms;
+        ts.d_trans2 = nullptr;
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (d_desc) (void)hipFree(d_desc);
+    if (d_sink) (void)hipFree(d_sink);
+    if (ok) {
+        ts.d_trans2 = d_tab;
+        ts.trans2_entries = entries;
+        ts.trans2_state = 1;
     } else {
         if (d_tab) (void)hipFree(d_tab);
         (void)hipGetLastError();
@@ -774,19 +880,27 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
         p.order = d_order;
         p.no_jump = (flags & BILD_NO_JUMP) || getenv("BILD_NO_JUMP") ? 1 : 0;
         if (mode == kModal && K1 > 0 && !(flags & BILD_NO_PREFIX)) {
-            const int64_t seen = (flags & kBuildTransients) ? 0 : (ts.evals_seen += n);
+            const int64_t seen = tl_building ? 0 : (ts.evals_seen += n);
             static const char *after_env = getenv("BILD_TABLES_AFTER"); // experiments only: delay the tables
             const int64_t prefix_after = after_env ? atoll(after_env) : kPrefixAfter;
             const int64_t transients_after = after_env ? atoll(after_env) : kTransientsAfter;
             if (ts.prefix_state == 0 && seen >= prefix_after) ensure_prefix(m, ts, st);
             if (ts.prefix_state == 1) p.prefix = ts.d_prefix;
-            if (flags & kBuildTransients) {
+            if (tl_building == 1) {
                 p.trans_dump = ts.d_trans;
+            } else if (tl_building == 2) {
+                p.trans2_dump = ts.d_trans2;
+                p.gap_max = ts.gap_max;
             } else if (p.prefix && !p.no_jump) {
                 if (ts.trans_state == 0 && seen >= transients_after) ensure_transients(m, ts, st);
                 if (ts.trans_state == 1) {
                     p.trans = ts.d_trans;
                     p.m_typ = ts.trans_m_typ;
+                    if (ts.trans2_state == 0) ensure_pairs(m, ts, st);
+                    if (ts.trans2_state == 1) {
+                        p.trans2 = ts.d_trans2;
+                        p.gap_max = ts.gap_max;
+                    }
                 }
             }
         }
@@ -870,6 +984,7 @@ bool schedule(const bild_model &m, const bild_trajset &ts, int64_t n, int K1, co
     Geometry geom{};
     if (!geometry_for(m.NPm[mode], mode, n * ts.dstar_max, ts.means_max, &geom)) return false;
     const int Tmax = ts.Tmax, m_typ = ts.trans_m_typ;
+    const bool pairs = ts.trans2_state == 1;
     std::vector<int32_t> count((size_t)Tmax + 2, 0), work((size_t)n);
     for (int64_t r = 0; r < n; ++r) {
         const TrajDesc &td = ts.descs[traj_id ? traj_id[r] : 0];
@@ -885,21 +1000,25 @@ bool schedule(const bild_model &m, const bild_trajset &ts, int64_t n, int K1, co
             // least m_typ frames long (the table's typical frames-to-convergence) comes out of the transient table, unless a
             // run is in progress, which then ends m_typ frames behind it; shorter segments chain into one run.  (Boundaries
             // that switch nothing are rare and only blur the estimate.)
-            int run_from = -1;
+            int run_from = -1, links = 0;
             for (int i = 1; i < K1; ++i) {
                 const int t = a[i];
                 if (t >= T) break;
-                const int nxt = (i + 1 < K1 && a[i + 1] < T) ? a[i + 1] : T;
-                if (nxt - t >= m_typ) {
-                    if (run_from >= 0) {
-                        w += t + m_typ - run_from;
+                const int gap = ((i + 1 < K1 && a[i + 1] < T) ? a[i + 1] : T) - t;
+                if (run_from < 0) {
+                    if (gap < m_typ) {
+                        run_from = t;
+                        links = 1;
+                    }
+                } else {
+                    ++links;
+                    if (gap >= m_typ) {
+                        if (!(pairs && links == 2)) w += t + m_typ - run_from; // two switches: out of the pair table
                         run_from = -1;
                     }
-                } else if (run_from < 0) {
-                    run_from = t;
                 }
             }
-            if (run_from >= 0) w += T - run_from;
+            if (run_from >= 0 && !(links == 1 || (pairs && links == 2))) w += T - run_from;
             w = w > Tmax ? Tmax : w;
         }
         work[r] = w;
@@ -1280,6 +1399,7 @@ int bild_trajset_destroy(bild_trajset *ts)
     if (ts->d_descs) (void)hipFree(ts->d_descs);
     if (ts->d_prefix) (void)hipFree(ts->d_prefix);
     if (ts->d_trans) (void)hipFree(ts->d_trans);
+    if (ts->d_trans2) (void)hipFree(ts->d_trans2);
     delete ts;
     return BILD_OK;
 }
@@ -1410,11 +1530,13 @@ int bild_frames_run_read(const bild_model *m, int64_t *frames)
 int bild_prefix_info(const bild_trajset *ts, int64_t *bytes, double *build_ms)
 {
     if (!ts) return fail(BILD_ERR_INVALID, "NULL handle");
-    const bool built = ts->prefix_state == 1, trans = ts->trans_state == 1;
+    const bool built = ts->prefix_state == 1, trans = ts->trans_state == 1, pairs = ts->trans2_state == 1;
     if (bytes)
         *bytes = (built ? ts->prefix_records * prefix_record_doubles(ts->model->NPm[kModal]) * (int64_t)sizeof(double) : 0) +
-                 (trans ? ts->trans_entries * (int64_t)sizeof(TransEntry) : 0);
-    if (build_ms) *build_ms = (built ? ts->prefix_build_ms : 0.0) + (trans ? ts->trans_build_ms : 0.0);
+                 (trans ? ts->trans_entries * (int64_t)sizeof(TransEntry) : 0) +
+                 (pairs ? ts->trans2_entries * (int64_t)sizeof(TransEntry) : 0);
+    if (build_ms)
+        *build_ms = (built ? ts->prefix_build_ms : 0.0) + (trans ? ts->trans_build_ms : 0.0) + (pairs ? ts->trans2_build_ms : 0.0);
     return BILD_OK;
 }
 

@@ -61,6 +61,10 @@ struct TransEntry {
     int32_t m;
     int32_t pad;
 };
+// Pair table (second level): two switches s -> sn at frame t and sn -> sm at frame t + g, g < gap_max, closer together than
+// the first transient needs -- entry at  (trans0 * S + (((e * S + s) * S + sn) * S + sm) * T + t) * gap_max + g:  m frames from
+// t until the filter sits on the switch-free filter of sm, and c = what those frames add beyond that filter's sums from
+// t on.  Chains of three and more switches are run frame by frame.
 
 // Prefix table (vector kernels, modal path): the filter state after frame t of a task that has not switched yet
 // depends only on (trajectory, covariance chain e, initial state s, t) -- not on the candidate profile.  It is
@@ -98,6 +102,9 @@ struct KParams {
     const TransEntry *trans; // transient table to take whole transients from, null: every transient is run
     TransEntry *trans_dump;  // non-null: this launch BUILDS the transient table (one task per entry, K1 = 2)
     int32_t m_typ;           // with `trans`: typical frames-to-convergence of a transient (wave priority by expected work)
+    const TransEntry *trans2; // pair table: two switches less than gap_max frames apart, taken as one transient
+    TransEntry *trans2_dump;  // non-null: this launch BUILDS the pair table (one task per entry, K1 = 3)
+    int32_t gap_max;          // gaps 1 .. gap_max - 1 have entries in the pair table
 };
 
 // launch geometry for a padded chain length
@@ -119,7 +126,8 @@ constexpr int group_image_doubles(int NP) { return (NP + kDMax) * NP; }
 // [per group: product image] [per group: the task's segment list, kSegLds (start, state) pairs]
 constexpr int kFrameCounters = 256; // words of the frames-run counter (KParams::frames_run), summed by the host
 constexpr int kSegLds = 16;
-constexpr int group_seg_doubles() { return kSegLds; } // 2 * kSegLds int32 (the list is cleaned in place)
+constexpr int kRowConsts = 2; // per-task constants the frame loop reads from LDS instead of holding (or spilling) registers: s2
+constexpr int group_seg_doubles() { return kSegLds + kRowConsts; } // 2 * kSegLds int32 (the list is cleaned in place) + constants
 constexpr int state_header_doubles(int NP) { return 3 * NP; }
 
 // host-callable launchers implemented in kernels.hip

@@ -221,7 +221,11 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
     double *const scratch = smem + lds_tab + (size_t)(wv * GPW + grp) * group_image_doubles(NP);
     // the task's segment list (K1 <= kSegLds): a switch then costs two LDS reads instead of two dependent L2 round trips
     int32_t *const seg_lds = reinterpret_cast<int32_t *>(smem + lds_tab + (size_t)(kWaves * GPW) * group_image_doubles(NP)) +
-                             (size_t)(wv * GPW + grp) * (2 * kSegLds);
+                             (size_t)(wv * GPW + grp) * (2 * group_seg_doubles());
+    // ... and the task's constants of the frame loop.  In a register such a value is live across the whole loop and the first
+    // to be spilled -- the reload (scratch memory, vmcnt) then sits in every frame and waits for the trajectory prefetch too
+    typedef __attribute__((address_space(3))) double lds_double_t;
+    lds_double_t *const row_const = (lds_double_t *)reinterpret_cast<double *>(seg_lds + 2 * kSegLds);
 
     int cidx[CPL];
     bool isC[CPL], hasImg[CPL];
@@ -255,6 +259,10 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
         }
         const int T = td->T;
         const double s2 = td->s2[e];
+        if (ROW) {
+            if (gl == 0) row_const[0] = s2;
+            wave_lds_fence();
+        }
         const int nd = td->ndims[e];
 
         bool isM[CPL];
@@ -337,21 +345,27 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
         // 136 -> 119 us for the 10k batch in array order, 116 -> 114 us in the scheduler's order
         // (profiles/r02_wave_priority.txt).  A matter of speed only.
         if (JUMP && seg_in_lds && p.trans != nullptr) {
-            int w = 0, run_from = -1;
+            int w = 0, run_from = -1, links = 0; // a chain: switches less than m_typ frames apart, run as one piece
             const int mt = p.m_typ;
+            const bool pairs = p.trans2 != nullptr;
             for (int i = 1; i < nseg; ++i) {
                 const int t1 = seg_lds[i];
-                const int nxt = (i + 1 < nseg) ? seg_lds[i + 1] : T;
-                if (nxt - t1 >= mt) {
-                    if (run_from >= 0) {
-                        w += t1 + mt - run_from;
+                const int gap = ((i + 1 < nseg) ? seg_lds[i + 1] : T) - t1;
+                if (run_from < 0) {
+                    if (gap < mt) {
+                        run_from = t1;
+                        links = 1;
+                    }
+                } else {
+                    ++links;
+                    if (gap >= mt) { // the chain ends m_typ frames behind this switch
+                        if (!(pairs && links == 2)) w += t1 + mt - run_from;
                         run_from = -1;
                     }
-                } else if (run_from < 0) {
-                    run_from = t1;
                 }
             }
-            if (run_from >= 0) w += T - run_from;
+            // a chain that reaches the end of the trajectory: one switch, or two with the pair table, are table entries too
+            if (run_from >= 0 && !(links == 1 || (pairs && links == 2))) w += T - run_from;
             if (__ballot(w >= BILD_PRIO_T3)) __builtin_amdgcn_s_setprio(3);
             else if (__ballot(w >= BILD_PRIO_T2)) __builtin_amdgcn_s_setprio(2);
             else if (__ballot(w >= BILD_PRIO_T1)) __builtin_amdgcn_s_setprio(1);
@@ -430,7 +444,7 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
             if constexpr (ROW) {
                 // C w is never gathered: lane i of the row holds (C w)_i in ev and every use reads it by row broadcast
                 dpp_ready(ev[0]);
-                double sa = s2, sb2 = 0.0;
+                double sa = row_const[0], sb2 = 0.0; // s2
                 RowOps<NP>::dot(sa, sb2, ev[0], wq);
                 const double Sv = sa + sb2;
                 double Sinv = __builtin_amdgcn_rcp(Sv);
@@ -620,7 +634,7 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
         constexpr double kJumpTol = 1.1368683772161603e-13; // 2^-43
         const bool restore = !DUMP && p.prefix != nullptr;
         const bool jumping = JUMP && restore && !p.no_jump;
-        const bool building_transients = jumping && p.trans_dump != nullptr;
+        const bool building_transients = jumping && (p.trans_dump != nullptr || p.trans2_dump != nullptr);
         const bool use_transients = jumping && p.trans != nullptr && !building_transients;
         auto record_of = [&](int st, int t) { return p.prefix + (td->prefix_rec0 + ((int64_t)e * S + st) * T + t) * REC; };
         auto record = [&](int t) { return record_of(s, t); };
@@ -705,12 +719,28 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
                 const int t3 = nn < T ? nn : T;
                 const TransEntry en = p.trans[td->trans0 + (((int64_t)e * S + s) * S + sn) * T + t];
                 const double la = record_of(sn, t - 1)[kRecL], lb = record_of(sn, t3 - 1)[kRecL];
-                if (en.m <= 0 || t + en.m > t3) break; // the transient reaches into the next switch: run it
-                extra += en.c + (lb - la);
-                ++seg;
-                s = sn;
-                next_start = nn;
-                t = t3;
+                if (en.m > 0 && t + en.m <= t3) {
+                    extra += en.c + (lb - la);
+                    ++seg;
+                    s = sn;
+                    next_start = nn;
+                    t = t3;
+                    continue;
+                }
+                // the transient reaches into the next switch: the two together may be in the pair table
+                if (p.trans2 == nullptr || nn >= T || nn - t >= p.gap_max || nn <= t) break;
+                const int sm = seg_state_of(seg + 2);
+                if (sm == sn) break; // (uncleaned list)
+                const int n4 = (seg + 3 < nseg) ? seg_start_of(seg + 3) : INT_MAX;
+                const int t4 = n4 < T ? n4 : T;
+                const TransEntry e2 =
+                    p.trans2[(td->trans0 * S + ((((int64_t)e * S + s) * S + sn) * S + sm) * T + t) * p.gap_max + (nn - t)];
+                if (e2.m <= 0 || t + e2.m > t4) break; // a chain of three or more: run it
+                extra += e2.c + (record_of(sm, t4 - 1)[kRecL] - record_of(sm, t - 1)[kRecL]);
+                seg += 2;
+                s = sm;
+                next_start = n4;
+                t = t4;
             }
         };
         if (jumping) {
@@ -765,6 +795,13 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
             if constexpr (DUMP) dump(t);
             ++t;
             ++nrun;
+            if constexpr (JUMP) {
+                // The next frame's data were asked for at the top of this one: take delivery HERE, a whole frame later, and
+                // not where the register allocator happens to copy them (mid-frame: a wave with the SIMD to itself -- the
+                // long chains that end a launch -- then waited for L2 in every frame: 0.45 us per frame instead of 0.24)
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) asm volatile("" : "+v"(xn[q]));
+            }
             if (JUMP && jumping && t == t_check && t < T) {
 #if defined(BILD_TASK_CLOCK) && BILD_TASK_CLOCK == 2
                 const unsigned long long ev0 = wall_clock64();
@@ -821,14 +858,20 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
         if (building_transients) {
             // what this transient adds beyond the running sums of the new state's own filter over the same frames, and how
             // many frames it took (frames < t are processed; it started at the switch, frame t0)
-            const int t0 = seg_start_of(1), s_old = seg_state_of(0), tb = t < T ? t : T;
+            // (the descriptor as given: a second switch behind the trajectory's end has been cleaned away, its entry is void)
+            const int t0 = sst[1], s_old = ssv[0], tb = t < T ? t : T;
+            const bool all_switched = nseg == K1 && seg == nseg - 1; // converged (or ended) behind the LAST switch
             const double c = extra - (record_of(s, tb - 1)[kRecL] - record_of(s, t0 - 1)[kRecL]);
             if (gl == 0) {
                 TransEntry en;
-                en.c = c;
-                en.m = tb - t0;
+                en.c = all_switched ? c : 0.0;
+                en.m = all_switched ? tb - t0 : 0;
                 en.pad = 0;
-                p.trans_dump[td->trans0 + (((int64_t)e * S + s_old) * S + s) * T + t0] = en;
+                if (p.trans2_dump)
+                    p.trans2_dump[(td->trans0 * S + ((((int64_t)e * S + s_old) * S + ssv[1]) * S + ssv[2]) * T + t0) * p.gap_max +
+                                  (sst[2] - t0)] = en;
+                else
+                    p.trans_dump[td->trans0 + (((int64_t)e * S + s_old) * S + ssv[1]) * T + t0] = en;
                 p.out[otask] = 0.0;
             }
         } else if (gl == 0) {

@@ -622,12 +622,19 @@ def test_baseline_config4_full_samples_per_trajectory(built_lib):
         assert worst < TOL, (path, worst)
         results[path] = got
     assert np.max(np.abs(results['auto'] - results['dense'])) < TOL
-    # one trajectory at a time through the sampler seam: same numbers as in the fused batch, bit for bit
+    # placement inside a batch, the batch's size and its order do not matter, bit for bit -- on the same trajectory set
     model.path = 'auto'
     for j in (1, 5):
         sl = slice(j * per, (j + 1) * per)
+        alone = model.logL_segments(seg_start[sl][::-1], seg_state[sl][::-1], trajs, tid[sl][::-1])[::-1]
+        assert np.array_equal(alone, results['auto'][sl])
+    # one trajectory at a time through the sampler seam: a trajectory set of its own, small enough for the pair table
+    # (api.cpp: ensure_pairs) that the set of six does not get -- the pieces of a sum are cut differently, the values agree
+    # to rounding (1e-11 observed), not to the bit
+    for j in (1, 5):
+        sl = slice(j * per, (j + 1) * per)
         sampler = bild_amd.FixedkSampler(trajs[j], model, k=k, N=per, max_fcomplete=0)
-        assert np.array_equal(sampler.logL(ss[sl], thetas[sl]), results['auto'][sl])
+        assert np.max(np.abs(sampler.logL(ss[sl], thetas[sl]) - results['auto'][sl])) < 1e-9
 
 
 def test_baseline_config5_full_inference(built_lib):
@@ -929,6 +936,75 @@ def test_prefix_table_and_launch_order_do_not_change_results(built_lib, case):
     print(case, {k_: round(v, 3) for k_, v in shares.items()})
     assert 0.97 < shares['frame by frame'] <= 1.0          # frame 0 is not counted
     assert shares['table + jumps'] < shares['table'] < shares['frame by frame']
+
+
+@pytest.mark.parametrize('S', [2, 3])
+def test_pair_table_two_close_switches_run_no_frame(built_lib, S):
+    """
+    Second-level transient table (csrc/common.h "pair table", api.cpp ensure_pairs): two switches closer together than the
+    first one's transient come out of ONE entry, keyed by (old, middle, new state, frame, gap).  Designed candidates:
+    pairs at every kind of place (frame 1, mid-trajectory, the second switch on the last frame / beyond the end), gaps
+    from 1 up to beyond the table's range, followed by nothing, by a far third switch, or by a near one (a chain of
+    three, which is run).  Results equal the frame-by-frame run and the oracle; the pairs inside the table's range run
+    no frame at all (counted on the device).
+    """
+    import ctypes
+    import torch
+    import bild_amd
+    from bild_amd import _lib
+    rng = np.random.default_rng(77 + S)
+    T = 500
+    model = bild_amd.MultiStateRouse(20, 1, 5, d=3, looppositions=H.LOOPS[S], localization_error=0.1)
+    traj = model.trajectory_from_loopingprofile(H.random_profile(rng, T, S, 100), missing_frames=0.04, rng=rng)
+    BIG = np.int32(2 ** 31 - 1)
+    rows, kinds = [], []
+    for t in (1, 2, 37, 250, 430, 470, 495, 498):
+        for g in (1, 2, 5, 11, 20, 33, 47, 63, 64, 65, 90):
+            for tail in ('none', 'far', 'near'):
+                t2 = t + g
+                t3 = {'none': BIG, 'far': t2 + 150, 'near': t2 + 6}[tail]
+                rows.append([0, t, t2, t3])
+                kinds.append((t, g, tail))
+    seg_start = np.array(rows, dtype=np.int32)
+    n = len(seg_start)
+    seg_state = np.zeros((n, 4), dtype=np.int32)
+    seg_state[:, 0] = rng.integers(S, size=n)
+    for i in range(1, 4):                                   # every boundary a real switch; S = 3: both A-B-A and A-B-C
+        step = rng.integers(1, S, size=n)
+        seg_state[:, i] = (seg_state[:, i - 1] + step) % S
+    h, ts = model.handle(), model.trajset(traj)
+    base = _lib.logl_segments(h, ts, seg_start, seg_state, None, prefix=False)
+    fast = _lib.logl_segments(h, ts, seg_start, seg_state, None)
+    print(f"S={S}: max |tables - frame by frame| = {np.max(np.abs(fast - base)):.2e}")
+    assert np.max(np.abs(fast - base)) < 1e-9
+    pick = rng.choice(n, 40, replace=False)
+    assert _spot_check(model, [traj], seg_start[pick], seg_state[pick], np.zeros(len(pick), np.int32), fast[pick], rng, len(pick), [T]) < TOL
+    # frames run per candidate
+    dev = torch.device('cuda', 0)
+    da, db = torch.from_numpy(seg_start).to(dev), torch.from_numpy(seg_state).to(dev)
+    out = torch.empty(n, dtype=torch.float64, device=dev)
+    frames = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    _lib.lib().bild_debug_frames_per_task(ctypes.c_void_p(frames.data_ptr()))
+    try:
+        _lib.logl_segments_device(h, ts, n, 4, da.data_ptr(), db.data_ptr(), 0, out.data_ptr())
+        torch.cuda.synchronize()
+    finally:
+        _lib.lib().bild_debug_frames_per_task(None)
+    assert np.array_equal(out.cpu().numpy(), fast)
+    f = frames.cpu().numpy()
+    in_table = near = 0
+    for i, (t, g, tail) in enumerate(kinds):
+        t2, third_inside = t + g, int(seg_start[i, 3]) < T
+        if t2 >= T:
+            assert f[i] == 0, (kinds[i], f[i])               # a lone switch in front of the end: single table
+        elif g <= 20 and not (tail == 'near' and third_inside):
+            assert f[i] == 0, (kinds[i], f[i])               # the pair -- converged before the far third switch, or reaching
+            in_table += 1                                    # the end of the trajectory: one entry of the pair table
+        elif g <= 20:
+            assert f[i] > 0, (kinds[i], f[i])                # three close switches: run
+            near += 1
+    assert in_table >= 40 and near >= 20
+    assert _lib.prefix_info(ts)[0] > 0
 
 
 @pytest.mark.parametrize('d,err', [(4, 0.1), (5, [0.1, 0.1, 0.1, 0.1, 0.3]), (6, [0.2, 0.1, 0.2, 0.1, 0.2, 0.1]), (8, 0.15),
