@@ -868,6 +868,9 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
         if (lds > 160 * 1024)
             return fail(BILD_ERR_UNSUPPORTED, "model tables need %zu bytes of LDS (> 160 KiB): too many states (%d) for chain length %d", lds, m.S, m.n);
     }
+    // room for the walk plan (the table entries of all switches of a task, fetched at once) where it does not cost occupancy
+    const size_t walk_bytes = fam == kVector ? (size_t)geom.W * (64 / geom.G) * kWalkDoubles * sizeof(double) : 0;
+    const bool walk_fits = fam == kVector && K1 <= kSegLds && lds + walk_bytes <= (size_t)48 * 1024 && !getenv("BILD_NO_WALK_PLAN");
 
     KParams p{};
     fill_params(m, ts, mode, p);
@@ -900,6 +903,10 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
                     if (ts.trans2_state == 1) {
                         p.trans2 = ts.d_trans2;
                         p.gap_max = ts.gap_max;
+                    }
+                    if (walk_fits) {
+                        p.walk_lds = 1;
+                        lds += walk_bytes;
                     }
                 }
             }

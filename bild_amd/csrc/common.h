@@ -105,6 +105,7 @@ struct KParams {
     const TransEntry *trans2; // pair table: two switches less than gap_max frames apart, taken as one transient
     TransEntry *trans2_dump;  // non-null: this launch BUILDS the pair table (one task per entry, K1 = 3)
     int32_t gap_max;          // gaps 1 .. gap_max - 1 have entries in the pair table
+    int32_t walk_lds;         // the launch has kWalkDoubles of LDS per task behind the segment lists (see logl_kernel: walk plan)
 };
 
 // launch geometry for a padded chain length
@@ -129,6 +130,8 @@ constexpr int kSegLds = 16;
 constexpr int kRowConsts = 2; // per-task constants the frame loop reads from LDS instead of holding (or spilling) registers: s2
 constexpr int group_seg_doubles() { return kSegLds + kRowConsts; } // 2 * kSegLds int32 (the list is cleaned in place) + constants
 constexpr int state_header_doubles(int NP) { return 3 * NP; }
+// optional (KParams::walk_lds): the task's table entries, fetched for all its switches at once -- 3 doubles per switch
+constexpr int kWalkDoubles = 3 * kSegLds;
 
 // host-callable launchers implemented in kernels.hip
 int launch_logl(const Geometry &g, int mode, const KParams &p, int grid, size_t lds_bytes, void *stream);

@@ -226,6 +226,10 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
     // to be spilled -- the reload (scratch memory, vmcnt) then sits in every frame and waits for the trajectory prefetch too
     typedef __attribute__((address_space(3))) double lds_double_t;
     lds_double_t *const row_const = (lds_double_t *)reinterpret_cast<double *>(seg_lds + 2 * kSegLds);
+    // walk plan (p.walk_lds): per switch of the task, what the tables hold for it -- see `land`
+    lds_double_t *const walk =
+        (lds_double_t *)(smem + lds_tab + (size_t)(kWaves * GPW) * (group_image_doubles(NP) + group_seg_doubles())) +
+        (size_t)(wv * GPW + grp) * kWalkDoubles;
 
     int cidx[CPL];
     bool isC[CPL], hasImg[CPL];
@@ -373,6 +377,9 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
         }
         int seg = 0;
         int s = seg_state_of(0);
+#if defined(BILD_TASK_CLOCK) && BILD_TASK_CLOCK == 3
+        const unsigned long long clock_a = wall_clock64(); // descriptor read, segment list cleaned
+#endif
         int next_start = (nseg > 1) ? seg_start_of(1) : INT_MAX;
 
         // ---- per-state registers -------------------------------------------------
@@ -710,9 +717,64 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
             t_check = t0 + 8; // (a switch at t0 sets its own; lists too long to be cleaned may hold boundaries that switch nothing)
             open_run = true;
         };
+        // The walk plan.  Which table entries a task may need is known from its (cleaned) segment list alone: for the switch
+        // into segment i, the transient entry of (state i-1 -> state i, frame start_i) and, where segment i is shorter than the
+        // pair table's range, the pair entry of (state i-1 -> i -> i+1, start_i, length of segment i) -- each with the running
+        // sums of the new state's filter up to the switch behind.  Lane i - 1 of the task fetches those of switch i, all at
+        // once, and leaves the two sums and the two frame counts in LDS; `land` then walks from switch to switch without
+        // waiting for memory (four switches: 6.6 -> ~2 us of a task's life; the same numbers, added in the same order).
+        const bool planned = use_transients && p.walk_lds != 0 && seg_in_lds;
+        if (planned) {
+            for (int i = 1 + gl; i < nseg; i += (BLK || ROW) ? 16 : G) {
+                const int ti = seg_lds[i], s0 = seg_lds[kSegLds + i - 1], s1 = seg_lds[kSegLds + i];
+                const int n2 = (i + 1 < nseg) ? seg_lds[i + 1] : INT_MAX;
+                const int t3 = n2 < T ? n2 : T;
+                const TransEntry en = p.trans[td->trans0 + (((int64_t)e * S + s0) * S + s1) * T + ti];
+                const double la = record_of(s1, ti - 1)[kRecL], lb = record_of(s1, t3 - 1)[kRecL];
+                double v2 = 0.0;
+                int m2 = 0;
+                if (p.trans2 != nullptr && n2 < T && n2 - ti < p.gap_max) {
+                    const int sm = seg_lds[kSegLds + i + 1];
+                    const int n4 = (i + 2 < nseg) ? seg_lds[i + 2] : INT_MAX;
+                    const int t4 = n4 < T ? n4 : T;
+                    const TransEntry e2 =
+                        p.trans2[(td->trans0 * S + ((((int64_t)e * S + s0) * S + s1) * S + sm) * T + ti) * p.gap_max + (n2 - ti)];
+                    v2 = e2.c + (record_of(sm, t4 - 1)[kRecL] - record_of(sm, ti - 1)[kRecL]);
+                    m2 = e2.m;
+                }
+                walk[3 * i] = en.c + (lb - la);
+                walk[3 * i + 1] = v2;
+                walk[3 * i + 2] = __hiloint2double(m2, en.m);
+            }
+            wave_lds_fence();
+        }
         // at a synchronised point in front of frame t (== next_start, or T): take whatever the tables hold
         auto land = [&]() {
-            while (t < T && use_transients) {
+            while (planned && t < T) { // t == start of segment seg + 1
+                const int i = seg + 1;
+                const double v1 = walk[3 * i], v2 = walk[3 * i + 1], mm = walk[3 * i + 2];
+                const int m1 = __double2loint(mm), m2 = __double2hiint(mm);
+                const int nn = (seg + 2 < nseg) ? seg_start_of(seg + 2) : INT_MAX;
+                const int t3 = nn < T ? nn : T;
+                if (m1 > 0 && t + m1 <= t3) {
+                    extra += v1;
+                    ++seg;
+                    s = seg_state_of(seg);
+                    next_start = nn;
+                    t = t3;
+                    continue;
+                }
+                if (m2 <= 0) break;
+                const int n4 = (seg + 3 < nseg) ? seg_start_of(seg + 3) : INT_MAX;
+                const int t4 = n4 < T ? n4 : T;
+                if (t + m2 > t4) break;
+                extra += v2;
+                seg += 2;
+                s = seg_state_of(seg);
+                next_start = n4;
+                t = t4;
+            }
+            while (!planned && t < T && use_transients) {
                 const int sn = seg_state_of(seg + 1);
                 if (sn == s) break; // (uncleaned list) not a switch: run on
                 const int nn = (seg + 2 < nseg) ? seg_start_of(seg + 2) : INT_MAX;
@@ -743,6 +805,10 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
                 t = t4;
             }
         };
+#if defined(BILD_TASK_CLOCK) && BILD_TASK_CLOCK == 3
+        const unsigned long long clock_b = wall_clock64(); // state vectors loaded, lambdas set up
+        unsigned long long clock_c = clock_b;
+#endif
         if (jumping) {
             open_run = false;
             t = next_start < 1 ? 1 : (next_start < T ? next_start : T); // first switch (>= 1: segment 0 owns frame 0), or T
@@ -750,6 +816,9 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
                 extra = record(t - 1)[kRecL];
                 land();
             }
+#if defined(BILD_TASK_CLOCK) && BILD_TASK_CLOCK == 3
+            clock_c = wall_clock64(); // tables walked
+#endif
             if (t < T) start_run(t, false);
         } else if (restore) {
             t = next_start < 1 ? 1 : (next_start < T ? next_start : T);
@@ -882,6 +951,11 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
         if (p.frames_run && gl == 0) atomicAdd(p.frames_run + (blockIdx.x % kFrameCounters), (unsigned long long)nrun);
 #ifdef BILD_TASK_CLOCK
         if (p.frames_task && gl == 0)
+#if BILD_TASK_CLOCK == 3
+            p.frames_task[otask] = (int32_t)(((((clock_a - clock_begin) / 2) & 0x3ff) << 20) | ((((clock_b - clock_begin) / 2) & 0x3ff) << 10) |
+                                             (((clock_c - clock_begin) / 2) & 0x3ff));
+        else if (false)
+#endif
             p.frames_task[otask] = BILD_TASK_CLOCK == 2 ? (int32_t)(((clock_events & 0xffffull) << 16) | (unsigned)n_events)
                                                         : (int32_t)(((clock_begin & 0xffffull) << 16) | (wall_clock64() & 0xffffull));
 #else

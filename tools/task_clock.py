@@ -54,7 +54,7 @@ T = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 k = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 for use_order in (0, 1):
     res = {}
-    names = ('norm', 'clock') + (('events',) if os.path.exists(os.path.join(VDIR, 'libbild_amd_events.so')) else ())
+    names = ('norm', 'clock') + tuple(x for x in ('events', 'stages') if os.path.exists(os.path.join(VDIR, f'libbild_amd_{x}.so')))
     for name in names:
         path = f'/tmp/task_clock_{name}.npy'
         env = dict(os.environ, BILD_AMD_LIB=os.path.join(VDIR, f'libbild_amd_{name}.so'))
@@ -103,3 +103,9 @@ for use_order in (0, 1):
             if m.any():
                 print(f"   candidates with {lo:3d}..{hi:4d} frames: {m.sum():5d}: task {dur[m].mean():6.1f} us, of it events {ev_us[m].mean():5.1f} us "
                       f"({ev_n[m].mean():.1f} of them), rest per frame {(dur[m].mean() - ev_us[m].mean() - 13.) / f[m].mean():.3f} us")
+    if 'stages' in res:     # -DBILD_TASK_CLOCK=3: stamps inside the per-task prologue, 20 ns units since the task began
+        v = res['stages'].astype(np.int64) & 0x3fffffff
+        ta, tb, tc = ((v >> 20) & 0x3ff) / 50., ((v >> 10) & 0x3ff) / 50., (v & 0x3ff) / 50.
+        idle = f == 0
+        print(f"   prologue of candidates that run no frame (us since the task began): descriptor + segment list {ta[idle].mean():.2f}, "
+              f"state vectors {tb[idle].mean():.2f}, tables walked {tc[idle].mean():.2f}, result written {dur[idle].mean():.2f}")
