@@ -267,6 +267,7 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
             if (gl == 0) row_const[0] = s2;
             wave_lds_fence();
         }
+        double s2_now = s2; // ROW: read again from LDS at the top of every frame (see row_const)
         const int nd = td->ndims[e];
 
         bool isM[CPL];
@@ -451,7 +452,7 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
             if constexpr (ROW) {
                 // C w is never gathered: lane i of the row holds (C w)_i in ev and every use reads it by row broadcast
                 dpp_ready(ev[0]);
-                double sa = row_const[0], sb2 = 0.0; // s2
+                double sa = s2_now, sb2 = 0.0;
                 RowOps<NP>::dot(sa, sb2, ev[0], wq);
                 const double Sv = sa + sb2;
                 double Sinv = __builtin_amdgcn_rcp(Sv);
@@ -549,8 +550,10 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
 #endif
         constexpr int kJumpFirst = BILD_JUMP_FIRST; // first comparison this many frames behind a switch
         int t_check = 0; // frame index (frames < t_check are processed) at which the next convergence check is due
+        int s_loaded = s; // state whose vectors (wq, L, sgd) are in registers
         // one frame t >= 1: state bookkeeping, predict (pyx:206-241), masked update (pyx:244-248)
         auto frame = [&](int t, const double (&xv)[CPL], double probe) {
+            if (ROW) s2_now = row_const[0];
             if (t >= next_start) {
                 do {
                     ++seg;
@@ -569,6 +572,7 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
                     }
                     s = sn;
                     load_state(s);
+                    s_loaded = s;
                     t_check = t + kJumpFirst;
                 }
             }
@@ -686,14 +690,13 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
         };
 
         int t = 1;
-        int nrun = 0;
-        int s_loaded = s;   // state whose vectors (wq, L, sgd) are in registers
+        int nrun = 0; // frames run: minus the first frame of the open run while it lasts, plus its last frame + 1 when it ends
         double extra = 0.0; // finished pieces: table differences, transient entries, own pieces that have ended
         bool open_run = true; // the accumulators hold a piece that is not in `extra` yet
         double xc[CPL], xn[CPL], pc, pn;
-        // start a run of own frames at frame t0 from the table's state in front of it (px / pprobe stand at frame 0)
-        int t_at = 0; // frame the trajectory pointers stand at
-        auto start_run = [&](int t0, bool cumulative) {
+        // start a run of own frames at frame t0 from the table's state in front of it; the trajectory pointers stand at
+        // frame t_ptr (0 at the start of a task, t + 1 inside the frame loop)
+        auto start_run = [&](int t0, bool cumulative, int t_ptr) {
             const double *__restrict__ rec = record(t0 - 1);
             load_cols(rec);
             if (cumulative) { // accumulators continue the table's (BILD_NO_JUMP: bit-identical to the run from frame 0)
@@ -710,10 +713,10 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
                 s_loaded = s;
             }
 #pragma unroll
-            for (int q = 0; q < CPL; ++q) px[q] += (int64_t)xstep[q] * (t0 - t_at);
-            if (!ALLVALID) pprobe += (int64_t)d * (t0 - t_at);
+            for (int q = 0; q < CPL; ++q) px[q] += (int64_t)xstep[q] * (t0 - t_ptr);
+            if (!ALLVALID) pprobe += (int64_t)d * (t0 - t_ptr);
             fetch(xn, pn); // frame t0 (or the first padding row)
-            t_at = t0 + 1;
+            nrun -= t0;
             t_check = t0 + 8; // (a switch at t0 sets its own; lists too long to be cleaned may hold boundaries that switch nothing)
             open_run = true;
         };
@@ -819,11 +822,12 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
 #if defined(BILD_TASK_CLOCK) && BILD_TASK_CLOCK == 3
             clock_c = wall_clock64(); // tables walked
 #endif
-            if (t < T) start_run(t, false);
+            if (t < T) start_run(t, false, 0);
         } else if (restore) {
             t = next_start < 1 ? 1 : (next_start < T ? next_start : T);
-            start_run(t, true);
+            start_run(t, true, 0);
         } else {
+            nrun = -1; // the run starts at frame 1
             fetch(xc, pc); // frame 0
             fetch(xn, pn); // frame 1 (or the first padding row)
             if (ALLVALID || !isnan(pc)) update(xc);
@@ -855,15 +859,9 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
             for (int q = 0; q < CPL; ++q) xc[q] = xn[q];
             pc = pn;
             fetch(xn, pn);
-            ++t_at;
-            {
-                const int s_before = s;
-                frame(t, xc, pc);
-                if (s != s_before) s_loaded = s;
-            }
+            frame(t, xc, pc);
             if constexpr (DUMP) dump(t);
             ++t;
-            ++nrun;
             if constexpr (JUMP) {
                 // The next frame's data were asked for at the top of this one: take delivery HERE, a whole frame later, and
                 // not where the register allocator happens to copy them (mid-frame: a wave with the SIMD to itself -- the
@@ -910,12 +908,14 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
                     // converged at frame t: the own piece ends here
                     extra += piece_value();
                     open_run = false;
+                    nrun += t;
                     if (building_transients) break;
+                    const int t_ptr = t + 1;
                     const int t2 = next_start < T ? next_start : T;
                     extra += record(t2 - 1)[kRecL] - rec[kRecL];
                     t = t2;
                     land();
-                    if (t < T) start_run(t, false);
+                    if (t < T) start_run(t, false, t_ptr);
                 }
 #if defined(BILD_TASK_CLOCK) && BILD_TASK_CLOCK == 2
                 clock_events += wall_clock64() - ev0;
@@ -923,7 +923,10 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
 #endif
             }
         }
-        if (open_run) extra += piece_value(); // a run that reached the end of the trajectory (all of it, without tables)
+        if (open_run) {
+            extra += piece_value(); // a run that reached the end of the trajectory (all of it, without tables)
+            nrun += t;
+        }
         if (building_transients) {
             // what this transient adds beyond the running sums of the new state's own filter over the same frames, and how
             // many frames it took (frames < t are processed; it started at the switch, frame t0)
