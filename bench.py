@@ -384,8 +384,10 @@ def main():
             roofline['same_kernel_frame_by_frame'] = {'kernel_ms': nkms, 'achieved': nexe / (nkms * 1e-3) / 1e12,
                                                       'frac': nexe / (nkms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                                                       'note': 'every frame of every candidate run (no prefix table): what the frame '
-                                                              'loop itself reaches of the fp64 peak; the default launch runs ~1/6 of '
-                                                              'the frames and is bound by dependent latencies (DESIGN.md section 4)'}
+                                                              'loop itself reaches of the fp64 peak; the default launch runs the '
+                                                              'share of the frames given in frames_executed_fraction (the rest comes '
+                                                              'out of tables) and lasts as long as its longest chain of close '
+                                                              'switches, run by one wavefront (DESIGN.md section 4)'}
             a_out = d_out[:n].cpu().numpy().copy()
             step(args.path)
             torch.cuda.synchronize()

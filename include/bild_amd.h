@@ -224,6 +224,19 @@ int bild_logl_segments_device(const bild_model *m, const bild_trajset *ts, int64
  * that does not converge runs every frame.  This changes results by ~1e-12 (differences of running sums, tolerance of
  * the comparison); BILD_NO_JUMP switches it off.  A result never depends on the other candidates of the batch.
  *
+ * Transient tables.  A transient that starts on the switch-free filter of the old state depends on (trajectory, chain,
+ * old state, new state, frame) only.  Right behind the prefix table the library lets the kernel evaluate one candidate
+ * per such switch and keeps how many frames the transient took to converge and what it added to the log-likelihood
+ * beyond the new state's own sums (16 bytes per entry).  A candidate whose next switch is at least that many frames
+ * away takes the entry and runs nothing.  Second level, the pair table: two switches closer together than the first
+ * one's transient, keyed by (old, middle, new state, frame, gap <= 64) -- built for trajectory sets where the build (a
+ * launch of T x gaps x S(S-1)^2 short tasks per trajectory) needs at most 2 M tasks; chains of three and more close
+ * switches are run frame by frame from the table's state in front of them.  All tables are built at the FIRST evaluation
+ * on a trajectory set and never later, and whether they are built depends on the set alone: results are reproducible
+ * bit for bit for a given trajectory set whatever was evaluated before, in whatever batches and order.  The same candidate
+ * evaluated on two different sets (one trajectory alone / among hundreds) may take its sums from different tables and
+ * agrees to ~1e-11.  BILD_NO_TRANSIENTS=1 / BILD_NO_PAIRS=1 (environment) switch a level off for experiments.
+ *
  * Candidates then differ in length, so the order in which they are dealt to wavefronts matters for speed (never for
  * results).  The host-buffer entry points schedule internally.  For device-resident candidates the caller may obtain
  * the launch order once (bild_schedule_segments, host arrays) and pass it, device-resident, to
@@ -249,7 +262,7 @@ int bild_frames_run_read(const bild_model *m, int64_t *frames);
 /* diagnostics: while d_buffer (device, one int32 per task = sample x localization-error chain) is set, every launch of
  * the vector kernels records how many frames each task ran itself; NULL switches it off */
 int bild_debug_frames_per_task(int32_t *d_buffer);
-/* size of the table in bytes (0: none built) and the device time its construction took */
+/* size of the tables (prefix, transient, pair) in bytes (0: none built) and the device time their construction took */
 int bild_prefix_info(const bild_trajset *ts, int64_t *bytes, double *build_ms);
 
 /* ---------------------------------------------------------- several GPUs ------------

@@ -40,6 +40,6 @@ print("   mean frames per in-range switch: %.1f" % (f.sum() / max(sw.sum(), 1)))
 for name, order in (('array order', np.arange(n)), ('sorted by frames (oracle schedule)', np.argsort(-f, kind='stable'))):
     g = f[order][: n // 4 * 4].reshape(-1, 4)
     wave = g.max(axis=1)
-    print(f"   waves of 4, {name}: mean wave length {wave.mean():.1f} (x{wave.mean() / f.mean():.2f} the mean row), longest wave {wave.max()}")
+    print(f"   waves of 4, {name}: mean wave length {wave.mean():.1f} (x{wave.mean() / max(f.mean(), 1e-9):.2f} the mean row), longest wave {wave.max()}")
 hist = np.bincount(np.minimum(f // 25, 20))
 print("   histogram (bins of 25 frames):", hist.tolist())
