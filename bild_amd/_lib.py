@@ -89,6 +89,7 @@ _SIGNATURES = {
     'bild_amis_restore': (ctypes.c_int, [_vp, ctypes.c_int64, _dp, _dp, ctypes.c_int64, _dp, _vp, _dp, _dp, _dp, _dp]),
     'bild_amis_sample_traces': (ctypes.c_int, [_vp, ctypes.c_int64, _dp, _vp]),
     'bild_amis_step': (ctypes.c_int, [_vp, ctypes.c_int64, _dp, _vp, _dp, _dp]),
+    'bild_amis_use_device': (ctypes.c_int, [_vp, ctypes.c_int]),
     'bild_interval_marginals': (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int64, _ip, _ip, _dp, _dp]),
     'bild_choice_counts': (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, _dp, _dp, _dp, ctypes.c_double, _vp, _vp, _vp, _vp]),
 }
@@ -501,6 +502,15 @@ class AmisCore:
         if code != OK:
             raise BildAmdError(code, "bild_amis_sample_traces failed")
         return thetas
+
+    def use_device(self, enable=True):
+        """ pooled samples in HBM, the passes of `step` on the GPU (bild_amis_use_device); for large batches per step """
+        code = lib().bild_amis_use_device(self._h, 1 if enable else 0)
+        if code == ERR_NO_DEVICE:
+            raise NoDeviceError(code, lib().bild_amis_error(self._h).decode())
+        if code != OK:
+            raise BildAmdError(code, lib().bild_amis_error(self._h).decode())
+        self.on_device = bool(enable)
 
     def step(self, ss, thetas, logLs):
         """ -> (logev, dlogev, KL); RuntimeError("Iteration did not converge") as the reference raises it """

@@ -425,10 +425,14 @@ class FixedkSampler:
                  max_fev=20000,
                  max_fcomplete=1000,
                  native=True,
+                 device_bookkeeping=None,
                  ):
         self.k = k
         self.N = N
         self.native = native
+        # where the native bookkeeping of a step runs: None = on the GPU for batches of >= 2000 samples per step when there
+        # is one (the passes over the pooled samples are then most of a step), else on the host; True / False force it
+        self.device_bookkeeping = device_bookkeeping
         self.brakes = (concentration_brake, polarization_brake)
         self.max_fev = max_fev
         self.max_fcomplete = max_fcomplete
@@ -462,9 +466,7 @@ class FixedkSampler:
         # step in tests/test_amis.py.
         self._core = None
         if native:
-            from . import _lib
-            self._core = _lib.AmisCore(model.transitions, self.parameters[0][0], self.parameters[0][1],
-                                       concentration_brake, polarization_brake, self.logprior)
+            self._core = self._new_core()
         # per proposal: concentration vector and CFC.lookup_tables, stacked
         self._As = np.empty((0, self.k + 1))
         self._heads = np.empty((0, self.cfc.n))
@@ -475,6 +477,23 @@ class FixedkSampler:
             self.fix_exhaustive()
         except FixedkSampler.ExhaustionImpractical:
             pass
+
+    def _new_core(self, on_device=None):
+        from . import _lib
+        self._core = _lib.AmisCore(self.model.transitions, self.parameters[0][0], self.parameters[0][1],
+                                   self.brakes[0], self.brakes[1], self.logprior)
+        if on_device is None:
+            self._place_core()
+        return self._core
+
+    def _place_core(self):
+        """ pooled samples to HBM (bild_amis_use_device) where that pays; `device_bookkeeping=True` insists """
+        from . import _lib
+        want = getattr(self, 'device_bookkeeping', None)
+        if want is None:
+            want = self.N >= 2000 and self.model.nStates * (self.k + 1) <= 64 and _lib.device_count() > 0
+        if want:
+            self._core.use_device(True)
 
     # -- pickling / copying: the native core is rebuilt from the pooled arrays ---------------------------
     def __getstate__(self):
@@ -490,12 +509,11 @@ class FixedkSampler:
         had_core = state.get('_core')
         self.__dict__.update(state)
         if had_core is not None and '_core' in state:
-            from . import _lib
             self.samples = _SampleList(self)
-            self._core = _lib.AmisCore(self.model.transitions, self.parameters[0][0], self.parameters[0][1],
-                                       self.brakes[0], self.brakes[1], self.logprior)
+            self._core = self._new_core(on_device=False)
             if had_core:
                 self._core.restore(self.parameters[1:], self._pool['ss'], self._pool['thetas'], self._arr_np)
+            self._place_core()
         elif 'samples' in state:
             self.samples = _SampleList(self)
 

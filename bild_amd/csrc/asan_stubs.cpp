@@ -3,6 +3,7 @@
 // (bild_trajset_create fails with BILD_ERR_NO_DEVICE first); the geometry tables are host code and are duplicated here
 // only as far as packing needs them (padded_rows), with the same values as kernels.hip.
 #include "common.h"
+#include "amis_math.h"
 
 namespace bild {
 int padded_rows(int n)
@@ -24,4 +25,8 @@ bool modal_mfma_supported(int NP) { return NP == 36 || NP == 40; }
 int launch_logl_modal_mfma(int, const KParams &, void *) { return 1; }
 size_t wide_lds_bytes(int) { return 0; }
 int launch_logl_wide(int, const KParams &, int, void *) { return 1; }
+int amis_dev_pass_a_rows(int64_t, int64_t) { return 0; }
+int amis_dev_pass_a(const AmisView &, int64_t, int64_t, int64_t, double, double *, double *, double *, double *, double *, int *) { return 1; }
+int amis_dev_pass_b(const AmisView &, int64_t, double, int, const double *, double *, double *, int) { return 1; }
+int amis_dev_pass_c(const AmisView &, int64_t, const double *, double, const double *, const double *, double *, int) { return 1; }
 } // namespace bild

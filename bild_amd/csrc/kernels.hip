@@ -749,6 +749,11 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
                 walk[3 * i + 1] = v2;
                 walk[3 * i + 2] = __hiloint2double(m2, en.m);
             }
+            // ... and, by the task's last lane (slot 0 belongs to no switch), the running sum in front of the first switch
+            if (gl == ((BLK || ROW) ? 15 : G - 1)) {
+                const int t1 = (nseg > 1 && seg_lds[1] < T) ? seg_lds[1] : T;
+                walk[0] = record_of(seg_lds[kSegLds], t1 - 1)[kRecL];
+            }
             wave_lds_fence();
         }
         // at a synchronised point in front of frame t (== next_start, or T): take whatever the tables hold
@@ -816,7 +821,7 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
             open_run = false;
             t = next_start < 1 ? 1 : (next_start < T ? next_start : T); // first switch (>= 1: segment 0 owns frame 0), or T
             if (!building_transients) {
-                extra = record(t - 1)[kRecL];
+                extra = planned ? (double)walk[0] : record(t - 1)[kRecL];
                 land();
             }
 #if defined(BILD_TASK_CLOCK) && BILD_TASK_CLOCK == 3

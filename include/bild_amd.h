@@ -344,6 +344,11 @@ int bild_amis_sample_traces(const bild_amis *m, int64_t N, const double *u, int6
  * bild_amis_error() == "Iteration did not converge" (the reference raises RuntimeError) */
 int bild_amis_step(bild_amis *m, int64_t N, const double *ss, const int64_t *thetas,
                    const double *logLs, double *evidence);
+/* keep the pooled samples in HBM and run the passes of bild_amis_step over them on the GPU (enable != 0), or return
+ * to the host implementation (0).  Same arithmetic per sample (csrc/amis_math.h); sums are formed per block in a fixed
+ * order, so results are reproducible and agree with the host's to rounding.  For batches of thousands of samples per
+ * step; BILD_ERR_UNSUPPORTED when n_states * (k + 1) > 64, BILD_ERR_NO_DEVICE without a GPU. */
+int bild_amis_use_device(bild_amis *m, int enable);
 
 /* Histograms behind the choice of the next k in the adaptive-k loop (reference
  * bild/choicesampler.py:115-210): rvs (samplesize x kmax) common random sample, mu (kmax)
