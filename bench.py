@@ -17,6 +17,7 @@ What the JSON line reports
                         kernel really executes (frames skipped through shared prefixes are not counted);
                         `canonical_equiv_frac` prices the same time against the reference's dense operation count
                         (a speed-up figure, may exceed 1, never a utilisation);
+  amis_step             a whole AMIS iteration around the seam (draws, likelihood, refit over all samples drawn so far);
   cpu_baseline          the reference's own Cython kernel on one host core (and on all cores, secondary).
 
 Multi-GPU: one process per GPU.  `--scaling weak` (default, what the driver runs): every rank evaluates its own 10k
@@ -369,6 +370,36 @@ def main():
         torch.cuda.synchronize()
         if not (world > 1 and args.scaling == 'strong'):
             result['api_seam']['max_abs_diff_vs_device_entry'] = float(np.max(np.abs(got - d_out[:n].cpu().numpy())))
+
+    if rank == 0 and world == 1 and args.scaling == 'weak' and not args.no_secondary and not args.no_seam:
+        # a whole AMIS iteration around the seam (bild/amis.py:805-906): draw N samples from the current
+        # proposal (NumPy, the reference's random stream), evaluate them, refit the proposal over ALL samples drawn so far
+        np.random.seed(7)
+        amis_sampler = bild_amd.FixedkSampler(trajs[0], model, k=k, N=n, max_fev=10 ** 9, max_fcomplete=0)
+        t_like = [0.0]
+        inner = amis_sampler.logL
+
+        def timed_logl(ss_, thetas_):
+            t0_ = time.perf_counter()
+            out_ = inner(ss_, thetas_)
+            t_like[0] += time.perf_counter() - t0_
+            return out_
+        amis_sampler.logL = timed_logl
+        for _ in range(3):
+            amis_sampler.step()
+        t_like[0] = 0.0
+        amis_steps = 8
+        t0 = time.perf_counter()
+        for _ in range(amis_steps):
+            amis_sampler.step()
+        adt = time.perf_counter() - t0
+        result['amis_step'] = {
+            'what': f'FixedkSampler.step() at N = {n}: draws + likelihood + weights / refit / evidence over the pool '
+                    f'({(3 + amis_steps) * n} samples at the end)',
+            'ms_per_step': adt / amis_steps * 1e3, 'likelihood_ms_per_step': t_like[0] / amis_steps * 1e3,
+            'bookkeeping': 'device (csrc/amis_device.hip)' if getattr(amis_sampler._core, 'on_device', False) else 'host (csrc/amis_host.cpp)',
+            'value': n * amis_steps / adt, 'unit': 'samples/s through whole AMIS iterations',
+        }
 
     if rank == 0 and world == 1 and args.scaling == 'weak':
         if not args.no_secondary and prefix_bytes:

@@ -773,7 +773,9 @@ int ensure_pairs(const bild_model &m, const bild_trajset &ts, hipStream_t st)
     if (G < 2) return BILD_OK;
     int64_t nb = 0;
     for (const TrajDesc &td : ts.descs) nb += (int64_t)std::max(td.T - 1, 0) * (G - 1) * S * (S - 1) * (S - 1);
-    if (nb == 0 || nb > ((int64_t)2 << 20)) return BILD_OK;
+    // (BILD_PAIRS_MAX_TASKS=<n>: another budget, for sets of many trajectories that will see hundreds of batches)
+    static const int64_t budget = getenv("BILD_PAIRS_MAX_TASKS") ? atoll(getenv("BILD_PAIRS_MAX_TASKS")) : ((int64_t)2 << 20);
+    if (nb == 0 || nb > budget) return BILD_OK;
     const int64_t entries = ts.trans_entries * S * G;
     const size_t bytes = (size_t)entries * sizeof(TransEntry);
     size_t free_b = 0, total_b = 0;

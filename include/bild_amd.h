@@ -235,7 +235,8 @@ int bild_logl_segments_device(const bild_model *m, const bild_trajset *ts, int64
  * on a trajectory set and never later, and whether they are built depends on the set alone: results are reproducible
  * bit for bit for a given trajectory set whatever was evaluated before, in whatever batches and order.  The same candidate
  * evaluated on two different sets (one trajectory alone / among hundreds) may take its sums from different tables and
- * agrees to ~1e-11.  BILD_NO_TRANSIENTS=1 / BILD_NO_PAIRS=1 (environment) switch a level off for experiments.
+ * agrees to ~1e-11.  BILD_NO_TRANSIENTS=1 / BILD_NO_PAIRS=1 (environment) switch a level off for experiments;
+ * BILD_PAIRS_MAX_TASKS=<n> replaces the 2 M budget (sets of many trajectories that will see hundreds of batches).
  *
  * Candidates then differ in length, so the order in which they are dealt to wavefronts matters for speed (never for
  * results).  The host-buffer entry points schedule internally.  For device-resident candidates the caller may obtain
