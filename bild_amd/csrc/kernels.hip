@@ -384,7 +384,11 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
         int next_start = (nseg > 1) ? seg_start_of(1) : INT_MAX;
 
         // ---- per-state registers -------------------------------------------------
-        double wq[NP]; // measurement vector in the current basis
+        // measurement vector in the current basis.  Row layout, jump instantiation: NOT kept in registers -- the same for
+        // all lanes of a row, it is read from the state header in LDS at the top of every update (five 16-byte reads, behind
+        // the predict), and the twenty registers go to the event paths, which otherwise spill around the frame loop
+        constexpr bool kWqFromLds = ROW && JUMP;
+        double wq[NP];
         // modal predict  C'_ij <- lam_i lam_j C'_ij + sig_i delta_ij,  M'_i <- lam_i M'_i  as ONE
         // fma per entry: L[q][i] = lam_i * (lam_c or 1), sgd[i] = sig_c on the own diagonal entry
         // (row i == column c of column slot q = i % CPL) and 0 elsewhere.  Rebuilt at switches.
@@ -393,8 +397,10 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
         double wown = 0.0; // block layout: w_c of the own covariance column, 0 for the other lanes
         auto load_state = [&](int st) {
             const double *__restrict__ sb = lds_hdr + (size_t)st * HDR; // lam | wq | sig at the offsets of the state block
+            if constexpr (!kWqFromLds) {
 #pragma unroll
-            for (int i = 0; i < NP; ++i) wq[i] = sb[StateBlock::wq(NP) + i];
+                for (int i = 0; i < NP; ++i) wq[i] = sb[StateBlock::wq(NP) + i];
+            }
             if (BLK) wown = isC[0] ? sb[StateBlock::wq(NP) + cidx[0]] : 0.0;
             if (MODE == kModal) {
                 double mu[CPL], sgc[CPL];
@@ -437,7 +443,21 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
         int nv = 0;     // observed frames behind these accumulators
 
         // ---- Kalman update (pyx:19-90) ---------------------------------------------
+        auto fetch_wq = [&]() { // (kWqFromLds) at the top of every update: issued behind the predict by the scheduler
+            if constexpr (kWqFromLds) {
+                typedef double __attribute__((ext_vector_type(2))) d2_t;
+                typedef const __attribute__((address_space(3))) d2_t *wq_ptr_t; // (the address moves with s: nothing to hoist)
+                const wq_ptr_t wp = (wq_ptr_t)(lds_hdr + (size_t)s * HDR + StateBlock::wq(NP));
+#pragma unroll
+                for (int i = 0; i < NP; i += 2) {
+                    const d2_t w2 = wp[i / 2];
+                    wq[i] = w2.x;
+                    wq[i + 1] = w2.y;
+                }
+            }
+        };
         auto update = [&](const double (&xv)[CPL]) {
+            fetch_wq();
             double ev[CPL];
 #pragma unroll
             for (int q = 0; q < CPL; ++q) {
