@@ -1042,10 +1042,30 @@ bool schedule(const bild_model &m, const bild_trajset &ts, int64_t n, int K1, co
         // are SPREAD: the heaviest go one per wave, the next heaviest fill the second rows, and so on -- a wave then holds
         // one long row and light ones instead of four long rows whose events add up.
         const int64_t rpw = geom.tasks_per_wave() % ts.dstar_max == 0 ? geom.tasks_per_wave() / ts.dstar_max : 1;
-        const int64_t nw = n / rpw, n_full = nw * rpw;
-        for (int64_t w = 0; w < nw; ++w)
-            for (int64_t j = 0; j < rpw; ++j) order[w * rpw + j] = sorted[j * nw + w];
-        for (int64_t i = n_full; i < n; ++i) order[i] = sorted[i]; // the lightest few: a last, partial wave
+        // ... round by round: the waves the chip holds at once (256 CUs x OCC workgroups x W waves) take the heaviest
+        // candidates that fit into them, spread as above; the next round the next heaviest, and so on.  A batch that fits
+        // the chip once is one round (plain spreading: the 10k batch, latency-bound by its longest chain); a batch many
+        // times that size with few busy candidates has them all in its first round.
+        // A batch of several rounds with more busy candidates than one round has waves is throughput-bound whatever the
+        // order: then candidates of equal work share a wave (the sorted order as it is), heaviest waves first
+        // (`profiles/r02_launch_order.txt`: 80 000 candidates 220 -> 157 us, configs[2]'s 256 000 1.77 -> 0.92 ms; a batch
+        // that fits the chip once is better off spread even when every wave has busy rows: 10 000 x k = 8, 123 vs 152 us).
+        static const char *mode_env = getenv("BILD_SCHED_MODE"); // experiments: "spread" / "sorted" whatever the batch
+        const int64_t slots = (int64_t)256 * geom.OCC * geom.W * rpw;
+        int64_t busy = 0;
+        while (busy < n && work[sorted[busy]] > 0) ++busy;
+        const bool packed = mode_env ? mode_env[1] == 'o' : (n > slots && busy > slots / rpw);
+        if (packed) {
+            std::copy(sorted.begin(), sorted.end(), order);
+            return true;
+        }
+        const int64_t round = (mode_env && mode_env[1] == 'p') ? n : std::max<int64_t>(slots, rpw);
+        for (int64_t base = 0; base < n; base += round) {
+            const int64_t cnt = std::min(round, n - base), nw = cnt / rpw, n_full = nw * rpw;
+            for (int64_t w = 0; w < nw; ++w)
+                for (int64_t j = 0; j < rpw; ++j) order[base + w * rpw + j] = sorted[base + j * nw + w];
+            for (int64_t i = n_full; i < cnt; ++i) order[base + i] = sorted[base + i]; // the lightest few: a last, partial wave
+        }
         return true;
     }
     const int64_t per_block = std::max<int64_t>(1, (int64_t)geom.W * geom.tasks_per_wave() / ts.dstar_max);

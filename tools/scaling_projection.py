@@ -21,7 +21,7 @@ os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER
 dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
 
 
-def kernel_and_wall(model, trajs, ss, thetas, tid, reps=20):
+def kernel_and_wall(model, trajs, ss, thetas, tid, reps=20, use_order=True):
     h = model.handle()
     ts = model.trajset(trajs if tid is not None else trajs[0])
     a, b = segments_from_st(ss, thetas, T)
@@ -29,9 +29,15 @@ def kernel_and_wall(model, trajs, ss, thetas, tid, reps=20):
     da, db = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
     dt_ = torch.from_numpy(tid).to(dev) if tid is not None else None
     out = torch.empty(n, dtype=torch.float64, device=dev)
+    d_order = [None]
     def go():
         _lib.logl_segments_device(h, ts, n, k + 1, da.data_ptr(), db.data_ptr(), dt_.data_ptr() if dt_ is not None else 0,
-                                  out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+                                  out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream,
+                                  d_order=d_order[0].data_ptr() if d_order[0] is not None else 0)
+    go()                                                    # builds the tables the scheduler's estimate needs
+    torch.cuda.synchronize()
+    if use_order:                                           # as bench.py: the launch order computed once per resident batch
+        d_order[0] = torch.from_numpy(np.asarray(_lib.schedule_segments(h, ts, a, b, tid))).to(dev)
     for _ in range(3):
         go()
     torch.cuda.synchronize()
@@ -62,7 +68,7 @@ def allgather_latency(n_local, world_equiv, reps=200):
 
 rng = np.random.default_rng(7)
 model = bild_amd.MultiStateRouse(20, 1., 5., d=3, localization_error=0.1)
-print("configs[1]: 10 000 candidates x 1 trajectory (T=1000, k=4), contiguous shards")
+print("configs[1]: 10 000 candidates x 1 trajectory (T=1000, k=4), contiguous shards, scheduler's launch order")
 traj = model.trajectory_from_loopingprofile(H.random_profile(rng, T, 2, 200), rng=rng)
 ss, thetas = H.candidate_profiles(rng, 10000, k, 2)
 base = None
@@ -75,7 +81,7 @@ for N in (1, 2, 4, 8):
     print(f"  N={N}: {n:6d} candidates per rank: kernel {kt * 1e6:7.1f} us, launch-to-done {wall * 1e6:7.1f} us, all_gather(world 1, {n} doubles) "
           f"{ag * 1e6:5.1f} us -> step {step * 1e6:7.1f} us = {10000 / step / 1e6:6.1f} M evals/s, x{base / step:4.2f} of N=1")
 
-print("configs[2]: 256 trajectories x 1 000 candidates (T=1000, k=4), whole trajectories per rank")
+print("configs[2]: 256 trajectories x 1 000 candidates (T=1000, k=4), whole trajectories per rank, scheduler's launch order")
 trajs = [model.trajectory_from_loopingprofile(H.random_profile(rng, T, 2, 200), rng=rng) for _ in range(256)]
 ss, thetas = H.candidate_profiles(rng, 256000, k, 2)
 base = None
