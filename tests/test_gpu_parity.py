@@ -938,6 +938,40 @@ def test_prefix_table_and_launch_order_do_not_change_results(built_lib, case):
     assert shares['table + jumps'] < shares['table'] < shares['frame by frame']
 
 
+def test_launch_order_of_a_throughput_bound_batch(built_lib):
+    """
+    Batches of several rounds with more busy candidates than one round has waves get the sorted launch order (candidates of
+    equal work share a wave), smaller ones the spread order (api.cpp: schedule).  Either way a permutation, and never a
+    different result: 30 000 candidates with six switches each on a short trajectory, against the same batch in array order.
+    """
+    import torch
+    import bild_amd
+    from bild_amd import _lib
+    from bild_amd.profiles import segments_from_st
+    rng = np.random.default_rng(31)
+    T, n, k = 300, 30000, 6
+    model = bild_amd.MultiStateRouse(20, 1, 5, d=3, localization_error=0.1)
+    traj = model.trajectory_from_loopingprofile(H.random_profile(rng, T, 2, 60), rng=rng)
+    ss, thetas = H.candidate_profiles(rng, n, k, 2)
+    a, b = segments_from_st(ss, thetas, T)
+    h, ts = model.handle(), model.trajset(traj)
+    want = _lib.logl_segments(h, ts, a, b, None)                       # host entry: array order
+    dev = torch.device('cuda', 0)
+    da, db = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    out = torch.empty(n, dtype=torch.float64, device=dev)
+    for count in (n, 9000):                                             # several rounds / one round
+        order = _lib.schedule_segments(h, ts, a[:count], b[:count])
+        assert np.array_equal(np.sort(order), np.arange(count))
+        d_order = torch.from_numpy(order).to(dev)
+        out.fill_(0.0)
+        _lib.logl_segments_device(h, ts, count, k + 1, da.data_ptr(), db.data_ptr(), 0, out.data_ptr(), d_order=d_order.data_ptr(),
+                                  validate=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy()[:count], want[:count])
+    pick = rng.choice(n, 24, replace=False)
+    assert _spot_check(model, [traj], a[pick], b[pick], np.zeros(len(pick), np.int32), want[pick], rng, len(pick), [T]) < TOL
+
+
 @pytest.mark.parametrize('S', [2, 3])
 def test_pair_table_two_close_switches_run_no_frame(built_lib, S):
     """
