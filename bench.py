@@ -18,6 +18,7 @@ What the JSON line reports
                         `canonical_equiv_frac` prices the same time against the reference's dense operation count
                         (a speed-up figure, may exceed 1, never a utilisation);
   amis_step             a whole AMIS iteration around the seam (draws, likelihood, refit over all samples drawn so far);
+  large_batch           twenty times the batch on the same trajectory: the throughput regime of the same kernel;
   cpu_baseline          the reference's own Cython kernel on one host core (and on all cores, secondary).
 
 Multi-GPU: one process per GPU.  `--scaling weak` (default, what the driver runs): every rank evaluates its own 10k
@@ -370,6 +371,28 @@ def main():
         torch.cuda.synchronize()
         if not (world > 1 and args.scaling == 'strong'):
             result['api_seam']['max_abs_diff_vs_device_entry'] = float(np.max(np.abs(got - d_out[:n].cpu().numpy())))
+
+    if rank == 0 and world == 1 and args.scaling == 'weak' and not args.no_secondary and n == 10000:
+        # the throughput regime of the same kernel: twenty times the batch on the same trajectory (the 10k headline is bound
+        # by the latency of its longest chain of close switches)
+        import helpers as H
+        n_big = 200000
+        rng_b = np.random.default_rng(4242)
+        ss_b, thetas_b = H.candidate_profiles(rng_b, n_big, k, args.states)
+        a_b, b_b = segments_from_st(ss_b, thetas_b, T)
+        da_b, db_b = torch.from_numpy(a_b).to(dev), torch.from_numpy(b_b).to(dev)
+        out_b = torch.empty(n_big, dtype=torch.float64, device=dev)
+        order_b = torch.from_numpy(_lib.schedule_segments(h, ts, a_b, b_b, None, path=args.path)).to(dev)
+
+        def big_step():
+            _lib.logl_segments_device(h, ts, n_big, k + 1, da_b.data_ptr(), db_b.data_ptr(), 0, out_b.data_ptr(),
+                                      stream=torch.cuda.current_stream().cuda_stream, path=args.path, d_order=order_b.data_ptr())
+        bdt, bkms, _ = timed(big_step, 10, 2)
+        result['large_batch'] = {
+            'what': f'{n_big} candidates on the same trajectory, resident in HBM, launch order of bild_schedule_segments',
+            'value': n_big * 10 / bdt, 'unit': 'evals/s', 'kernel_ms': bkms, 'frames_executed_fraction': timed.frames_per_launch / (n_big * T),
+        }
+        del da_b, db_b, out_b, order_b
 
     if rank == 0 and world == 1 and args.scaling == 'weak' and not args.no_secondary and not args.no_seam:
         # a whole AMIS iteration around the seam (bild/amis.py:805-906): draw N samples from the current
