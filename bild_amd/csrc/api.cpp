@@ -157,7 +157,7 @@ struct bild_model {
     // host-buffer entry points (one call at a time per model, call_mu): ONE packed device buffer
     // [seg_start | seg_state | traj_id] filled by one copy out of pinned staging, results back through
     // pinned staging, all on the model's own stream
-    mutable DeviceBuf ws_in, ws_out;
+    mutable DeviceBuf ws_in, ws_out, ws_sched; // ws_sched: workspace of the device-side launch order (schedule.hip)
     mutable PinnedBuf h_in, h_out;
     mutable hipStream_t stream = nullptr;
     mutable unsigned long long *d_frames = nullptr; // frames the tasks ran themselves, summed while kernel timing is on
@@ -1108,6 +1108,31 @@ bool schedule(const bild_model &m, const bild_trajset &ts, int64_t n, int K1, co
     return true;
 }
 
+// Launch order for a host-buffer call, computed on the device behind the upload (schedule.hip): only where it pays -- a
+// batch of several rounds on a trajectory set whose tables exist (from its second evaluation on); 1: no order (array order)
+int device_order(const bild_model &m, const bild_trajset &ts, int64_t n, int K1, const int32_t *d_start, const int32_t *d_tid,
+                 unsigned flags, hipStream_t st, const int32_t **d_order)
+{
+    if (n < 2 || K1 < 2 || n > INT_MAX || m.wide || m.mid || !m.modal_ok) return 1;
+    const unsigned path = flags & 0xFu;
+    if (path != BILD_PATH_AUTO && path != BILD_PATH_MODAL) return 1;
+    if ((flags & (BILD_NO_PREFIX | BILD_NO_JUMP)) || getenv("BILD_NO_PREFIX") || getenv("BILD_NO_JUMP") || getenv("BILD_NO_SCHEDULE")) return 1;
+    if (ts.prefix_state != 1 || ts.trans_state != 1) return 1;
+    Geometry geom{};
+    if (!geometry_for(m.NPm[kModal], kModal, n * ts.dstar_max, ts.means_max, &geom)) return 1;
+    if (geom.tasks_per_wave() % ts.dstar_max != 0) return 1;
+    const int rpw = geom.tasks_per_wave() / ts.dstar_max;
+    const int64_t slots = (int64_t)256 * geom.OCC * geom.W * rpw;
+    if (n <= slots) return 1; // one round: the order does not matter (10k batch: 80 vs 81 us)
+    const size_t bytes = device_schedule_bytes(n);
+    {
+        std::lock_guard<std::mutex> lk(m.mu);
+        if (m.ws_sched.reserve(bytes)) return 1;
+    }
+    return device_schedule(d_start, d_tid, ts.d_descs, K1, n, ts.trans_m_typ, ts.trans2_state == 1 ? 1 : 0, ts.Tmax, rpw, slots, m.ws_sched.ptr,
+                           m.ws_sched.cap, d_order, (void *)st);
+}
+
 // Host buffers in, host buffer out.  `fill(h_start, h_state)` writes the n x K1 run-length segments straight into
 // pinned staging memory (and validates them: these indices drive device addressing); then ONE host-to-device copy of
 // the packed block [seg_start | seg_state | traj_id], the launch, one device-to-host copy of the results, one
@@ -1168,6 +1193,10 @@ int run_staged(const bild_model *m, const bild_trajset *ts, int64_t n, int K1, c
     if (d_out_user) {
         HIP_TRY(hipEventRecord(m->h_in_event, st));
         m->h_in_busy = true;
+    }
+    if (!ordered) {
+        const int32_t *on_device = nullptr;
+        if (device_order(*m, *ts, n, K1, d_start, d_tid, flags, st, &on_device) == 0) d_order = on_device;
     }
     rc = launch_batch(*m, *ts, n, K1, d_start, d_state, d_tid, d_order, flags, st, d_out);
     if (rc) {
@@ -1255,6 +1284,7 @@ int bild_model_destroy(bild_model *m)
     }
     m->ws_in.release();
     m->ws_out.release();
+    m->ws_sched.release();
     m->h_in.release();
     m->h_out.release();
     if (m->h_in_busy) (void)hipEventSynchronize(m->h_in_event);

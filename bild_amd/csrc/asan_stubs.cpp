@@ -24,6 +24,8 @@ int launch_logl_dense_mfma(int, const KParams &, void *) { return 1; }
 bool modal_mfma_supported(int NP) { return NP == 36 || NP == 40; }
 int launch_logl_modal_mfma(int, const KParams &, void *) { return 1; }
 size_t wide_lds_bytes(int) { return 0; }
+size_t device_schedule_bytes(int64_t) { return 0; }
+int device_schedule(const int32_t *, const int32_t *, const TrajDesc *, int, int64_t, int, int, int, int, int64_t, void *, size_t, const int32_t **, void *) { return 1; }
 int launch_logl_wide(int, const KParams &, int, void *) { return 1; }
 int amis_dev_pass_a_rows(int64_t, int64_t) { return 0; }
 int amis_dev_pass_a(const AmisView &, int64_t, int64_t, int64_t, double, double *, double *, double *, double *, double *, int *) { return 1; }

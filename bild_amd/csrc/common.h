@@ -157,6 +157,10 @@ bool modal_mfma_supported(int NP);
 int launch_logl_modal_mfma(int NP, const KParams &p, void *stream);
 // chains of more than kMidMaxNP modes (wide.hip): one task per workgroup, state in LDS
 size_t wide_lds_bytes(int NP);
+// schedule.hip: launch order computed on the device (workspace of device_schedule_bytes(n); everything on `stream`)
+size_t device_schedule_bytes(int64_t n);
+int device_schedule(const int32_t *d_seg_start, const int32_t *d_traj_id, const TrajDesc *d_trajs, int K1, int64_t n, int m_typ, int pairs,
+                    int Tmax, int rpw, int64_t slots, void *ws, size_t ws_bytes, const int32_t **d_order, void *stream);
 int launch_logl_wide(int NP, const KParams &p, int grid, void *stream);
 
 } // namespace bild

@@ -1,0 +1,110 @@
+// Launch order of a batch whose candidates are not yet known to the host scheduler: the host-buffer entry points
+// (bild_logl_st, bild_logl_segments, ...) hand their descriptors to the device and launch at once.  For batches of
+// several rounds with many busy candidates the order is worth a factor of two in kernel time (api.cpp: schedule;
+// profiles/r02_launch_order.txt), and walking the lists on the host would cost more than that -- so the same estimate
+// (frames a candidate will run itself, from its switch frames and the tables' typical transient length) and the same
+// rule (sorted when throughput-bound, spread otherwise) run here, on the stream of the launch: one pass over the
+// segment lists, a radix sort of (work, index) pairs (hipCUB; stable, so the order is reproducible), one pass that
+// writes the order.  A matter of speed only: results never depend on the launch order (tests assert it bit for bit).
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include "common.h"
+
+namespace bild {
+namespace {
+
+__global__ void __launch_bounds__(256) work_kernel(const int32_t *__restrict__ seg_start, const int32_t *__restrict__ traj_id,
+                                                   const TrajDesc *__restrict__ trajs, int K1, int64_t n, int m_typ, int pairs, int Tmax,
+                                                   unsigned *__restrict__ keys, int32_t *__restrict__ idx,
+                                                   unsigned long long *__restrict__ busy)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int w = 0;
+    if (r < n) {
+        const int T = trajs[traj_id ? traj_id[r] : 0].T;
+        const int32_t *a = seg_start + r * K1;
+        // (as api.cpp: schedule) a chain = switches less than m_typ frames apart; one switch, or two with the pair table,
+        // come out of the tables
+        int run_from = -1, links = 0;
+        for (int i = 1; i < K1; ++i) {
+            const int t = a[i];
+            if (t >= T) break;
+            const int gap = ((i + 1 < K1 && a[i + 1] < T) ? a[i + 1] : T) - t;
+            if (run_from < 0) {
+                if (gap < m_typ) {
+                    run_from = t;
+                    links = 1;
+                }
+            } else {
+                ++links;
+                if (gap >= m_typ) {
+                    if (!(pairs && links == 2)) w += t + m_typ - run_from;
+                    run_from = -1;
+                }
+            }
+        }
+        if (run_from >= 0 && !(links == 1 || (pairs && links == 2))) w += T - run_from;
+        w = w > Tmax ? Tmax : (w < 0 ? 0 : w);
+        keys[r] = (unsigned)(Tmax - w); // ascending keys = descending work
+        idx[r] = (int32_t)r;
+    }
+    const unsigned long long any = __ballot(w > 0);
+    if ((threadIdx.x & 63) == 0 && any) atomicAdd(busy, (unsigned long long)__popcll(any));
+}
+
+__global__ void __launch_bounds__(256) order_kernel(const int32_t *__restrict__ sorted, int64_t n, int rpw, int64_t slots,
+                                                    const unsigned long long *__restrict__ busy, int32_t *__restrict__ order)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const bool packed = n > slots && (int64_t)*busy > slots / rpw;
+    if (packed) {
+        order[i] = sorted[i];
+        return;
+    }
+    const int64_t round = slots > rpw ? slots : rpw;
+    const int64_t base = (i / round) * round;
+    const int64_t cnt = (n - base < round) ? n - base : round, nw = cnt / rpw, li = i - base;
+    order[i] = li < nw * rpw ? sorted[base + (li % rpw) * nw + li / rpw] : sorted[i];
+}
+
+size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+} // namespace
+
+size_t device_schedule_bytes(int64_t n)
+{
+    size_t temp = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, temp, (const unsigned *)nullptr, (unsigned *)nullptr, (const int32_t *)nullptr,
+                                             (int32_t *)nullptr, (int)n, 0, 32, nullptr);
+    return 256 + 5 * align256((size_t)n * 4) + align256(temp) + 256;
+}
+
+int device_schedule(const int32_t *d_seg_start, const int32_t *d_traj_id, const TrajDesc *d_trajs, int K1, int64_t n, int m_typ, int pairs,
+                    int Tmax, int rpw, int64_t slots, void *ws, size_t ws_bytes, const int32_t **d_order, void *stream)
+{
+    if (n < 1 || n > 0x7fffffff || ws_bytes < device_schedule_bytes(n)) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    char *base = (char *)ws;
+    unsigned long long *busy = (unsigned long long *)base;
+    const size_t stride = align256((size_t)n * 4);
+    unsigned *keys_in = (unsigned *)(base + 256), *keys_out = (unsigned *)(base + 256 + stride);
+    int32_t *idx_in = (int32_t *)(base + 256 + 2 * stride), *idx_out = (int32_t *)(base + 256 + 3 * stride);
+    int32_t *order = (int32_t *)(base + 256 + 4 * stride);
+    void *temp = base + 256 + 5 * stride;
+    size_t temp_bytes = ws_bytes - (256 + 5 * stride);
+    if (hipMemsetAsync(busy, 0, sizeof(unsigned long long), st) != hipSuccess) return 1;
+    const int blocks = (int)((n + 255) / 256);
+    hipLaunchKernelGGL(work_kernel, dim3(blocks), dim3(256), 0, st, d_seg_start, d_traj_id, d_trajs, K1, n, m_typ, pairs, Tmax, keys_in, idx_in,
+                       busy);
+    int bits = 1;
+    while ((1u << bits) <= (unsigned)Tmax && bits < 32) ++bits;
+    if (hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, idx_in, idx_out, (int)n, 0, bits, st) != hipSuccess) return 1;
+    hipLaunchKernelGGL(order_kernel, dim3(blocks), dim3(256), 0, st, idx_out, n, rpw, slots, busy, order);
+    if (hipGetLastError() != hipSuccess) return 1;
+    *d_order = order;
+    return 0;
+}
+
+} // namespace bild

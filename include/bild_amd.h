@@ -239,7 +239,8 @@ int bild_logl_segments_device(const bild_model *m, const bild_trajset *ts, int64
  * BILD_PAIRS_MAX_TASKS=<n> replaces the 2 M budget (sets of many trajectories that will see hundreds of batches).
  *
  * Candidates then differ in length, so the order in which they are dealt to wavefronts matters for speed (never for
- * results).  The host-buffer entry points schedule internally.  For device-resident candidates the caller may obtain
+ * results).  The host-buffer entry points schedule internally (batches larger than the chip holds at once: on the device,
+ * behind the upload; BILD_NO_SCHEDULE=1 switches every scheduling off).  For device-resident candidates the caller may obtain
  * the launch order once (bild_schedule_segments, host arrays) and pass it, device-resident, to
  * bild_logl_segments_device_ordered: order[slot] = index of the sample evaluated in slot `slot`; a permutation of
  * 0..n-1 (checked only with BILD_VALIDATE_DEVICE).  NULL = the order of the arrays. */

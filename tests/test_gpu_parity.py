@@ -955,7 +955,10 @@ def test_launch_order_of_a_throughput_bound_batch(built_lib):
     ss, thetas = H.candidate_profiles(rng, n, k, 2)
     a, b = segments_from_st(ss, thetas, T)
     h, ts = model.handle(), model.trajset(traj)
-    want = _lib.logl_segments(h, ts, a, b, None)                       # host entry: array order
+    want = _lib.logl_segments(h, ts, a, b, None)                       # host entry, first evaluation on the set: array order
+    # ... from the second evaluation on the host entries order batches of several rounds on the device (schedule.hip)
+    assert np.array_equal(_lib.logl_segments(h, ts, a, b, None), want)
+    assert np.array_equal(_lib.logl_segments(h, ts, a[::-1].copy(), b[::-1].copy(), None)[::-1], want)
     dev = torch.device('cuda', 0)
     da, db = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
     out = torch.empty(n, dtype=torch.float64, device=dev)
