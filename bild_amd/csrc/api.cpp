@@ -774,40 +774,28 @@ int ensure_pairs(const bild_model &m, const bild_trajset &ts, hipStream_t st)
     int64_t nb = 0;
     for (const TrajDesc &td : ts.descs) nb += (int64_t)std::max(td.T - 1, 0) * (G - 1) * S * (S - 1) * (S - 1);
     // (BILD_PAIRS_MAX_TASKS=<n>: another budget, for sets of many trajectories that will see hundreds of batches)
-    static const int64_t budget = getenv("BILD_PAIRS_MAX_TASKS") ? atoll(getenv("BILD_PAIRS_MAX_TASKS")) : ((int64_t)2 << 20);
+    static const int64_t budget = getenv("BILD_PAIRS_MAX_TASKS") ? atoll(getenv("BILD_PAIRS_MAX_TASKS")) : ((int64_t)40 << 20);
     if (nb == 0 || nb > budget) return BILD_OK;
     const int64_t entries = ts.trans_entries * S * G;
     const size_t bytes = (size_t)entries * sizeof(TransEntry);
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes > free_b / 4) return BILD_OK;
-    std::vector<int32_t> host((size_t)7 * nb); // seg_start (3 per sample) | seg_state (3 per sample) | traj_id
-    int64_t r = 0;
+    // the build candidates -- seg_start (3 per task) | seg_state (3 per task) | traj_id -- are written on the device
+    // (schedule.hip: pair_tasks_kernel): up to tens of millions of them, nothing the host should fill and send
+    std::vector<int64_t> first((size_t)ts.n_traj + 1, 0);
     for (int j = 0; j < ts.n_traj; ++j)
-        for (int s = 0; s < S; ++s)
-            for (int sn = 0; sn < S; ++sn) {
-                if (sn == s) continue;
-                for (int sm = 0; sm < S; ++sm) {
-                    if (sm == sn) continue;
-                    for (int t = 1; t < ts.descs[j].T; ++t)
-                        for (int g = 1; g < G; ++g, ++r) {
-                            host[(size_t)3 * r] = 0;
-                            host[(size_t)3 * r + 1] = t;
-                            host[(size_t)3 * r + 2] = t + g; // beyond the end: the kernel voids the entry
-                            host[(size_t)3 * nb + 3 * r] = s;
-                            host[(size_t)3 * nb + 3 * r + 1] = sn;
-                            host[(size_t)3 * nb + 3 * r + 2] = sm;
-                            host[(size_t)6 * nb + r] = j;
-                        }
-                }
-            }
+        first[(size_t)j + 1] = first[j] + (int64_t)std::max(ts.descs[j].T - 1, 0) * (G - 1) * S * (S - 1) * (S - 1);
     int32_t *d_desc = nullptr;
+    int64_t *d_first = nullptr;
     double *d_sink = nullptr;
     TransEntry *d_tab = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    bool ok = hipMalloc((void **)&d_desc, host.size() * sizeof(int32_t)) == hipSuccess &&
+    bool ok = hipMalloc((void **)&d_desc, (size_t)7 * nb * sizeof(int32_t)) == hipSuccess &&
+              hipMalloc((void **)&d_first, first.size() * sizeof(int64_t)) == hipSuccess &&
               hipMalloc((void **)&d_sink, (size_t)nb * sizeof(double)) == hipSuccess &&
-              hipMalloc((void **)&d_tab, bytes) == hipSuccess && hipMemset(d_tab, 0, bytes) == hipSuccess &&
-              hipMemcpy(d_desc, host.data(), host.size() * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess &&
+              hipMalloc((void **)&d_tab, bytes) == hipSuccess && hipMemsetAsync(d_tab, 0, bytes, st) == hipSuccess &&
+              hipMemcpyAsync(d_first, first.data(), first.size() * sizeof(int64_t), hipMemcpyHostToDevice, st) == hipSuccess &&
+              launch_pair_tasks(d_first, ts.n_traj, ts.d_descs, S, G, nb, d_desc, d_desc + 3 * nb, d_desc + 6 * nb, (void *)st) == 0 &&
               hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
     if (ok) {
         ts.d_trans2 = d_tab; // launch_batch passes it on as the table to FILL (trans2_state is still -1)
@@ -825,7 +813,9 @@ int ensure_pairs(const bild_model &m, const bild_trajset &ts, hipStream_t st)
     }
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
+    if (!ok) (void)hipStreamSynchronize(st); // (`first` is read by an asynchronous copy)
     if (d_desc) (void)hipFree(d_desc);
+    if (d_first) (void)hipFree(d_first);
     if (d_sink) (void)hipFree(d_sink);
     if (ok) {
         ts.d_trans2 = d_tab;

@@ -24,6 +24,7 @@ int launch_logl_dense_mfma(int, const KParams &, void *) { return 1; }
 bool modal_mfma_supported(int NP) { return NP == 36 || NP == 40; }
 int launch_logl_modal_mfma(int, const KParams &, void *) { return 1; }
 size_t wide_lds_bytes(int) { return 0; }
+int launch_pair_tasks(const int64_t *, int, const TrajDesc *, int, int, int64_t, int32_t *, int32_t *, int32_t *, void *) { return 1; }
 size_t device_schedule_bytes(int64_t) { return 0; }
 int device_schedule(const int32_t *, const int32_t *, const TrajDesc *, int, int64_t, int, int, int, int, int64_t, void *, size_t, const int32_t **, void *) { return 1; }
 int launch_logl_wide(int, const KParams &, int, void *) { return 1; }

@@ -158,6 +158,8 @@ int launch_logl_modal_mfma(int NP, const KParams &p, void *stream);
 // chains of more than kMidMaxNP modes (wide.hip): one task per workgroup, state in LDS
 size_t wide_lds_bytes(int NP);
 // schedule.hip: launch order computed on the device (workspace of device_schedule_bytes(n); everything on `stream`)
+int launch_pair_tasks(const int64_t *d_first_task, int n_traj, const TrajDesc *d_trajs, int S, int G, int64_t nb, int32_t *d_seg_start,
+                      int32_t *d_seg_state, int32_t *d_traj_id, void *stream);
 size_t device_schedule_bytes(int64_t n);
 int device_schedule(const int32_t *d_seg_start, const int32_t *d_traj_id, const TrajDesc *d_trajs, int K1, int64_t n, int m_typ, int pairs,
                     int Tmax, int rpw, int64_t slots, void *ws, size_t ws_bytes, const int32_t **d_order, void *stream);

@@ -71,7 +71,47 @@ __global__ void __launch_bounds__(256) order_kernel(const int32_t *__restrict__ 
 
 size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
+// The candidates that build the pair table (api.cpp: ensure_pairs), written where they are needed: task r is
+// (trajectory j, s -> sn -> sm, first switch at t, second at t + g) in the order j, s, sn, sm, t, g.
+__global__ void __launch_bounds__(256) pair_tasks_kernel(const int64_t *__restrict__ first_task, int n_traj, const TrajDesc *__restrict__ trajs,
+                                                         int S, int G, int64_t nb, int32_t *__restrict__ seg_start,
+                                                         int32_t *__restrict__ seg_state, int32_t *__restrict__ traj_id)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nb) return;
+    int lo = 0, hi = n_traj; // first_task[lo] <= r < first_task[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (first_task[mid] <= r) lo = mid;
+        else hi = mid;
+    }
+    const int64_t local = r - first_task[lo];
+    const int T = trajs[lo].T;
+    const int64_t per_combo = (int64_t)(T - 1) * (G - 1);
+    const int combo = (int)(local / per_combo);
+    const int64_t rem = local - (int64_t)combo * per_combo;
+    const int t = 1 + (int)(rem / (G - 1)), g = 1 + (int)(rem % (G - 1));
+    const int s = combo / ((S - 1) * (S - 1)), rest = combo % ((S - 1) * (S - 1));
+    const int a = rest / (S - 1), b = rest % (S - 1);
+    const int sn = a < s ? a : a + 1, sm = b < sn ? b : b + 1;
+    seg_start[3 * r] = 0;
+    seg_start[3 * r + 1] = t;
+    seg_start[3 * r + 2] = t + g; // beyond the end: the kernel voids the entry
+    seg_state[3 * r] = s;
+    seg_state[3 * r + 1] = sn;
+    seg_state[3 * r + 2] = sm;
+    traj_id[r] = lo;
+}
+
 } // namespace
+
+int launch_pair_tasks(const int64_t *d_first_task, int n_traj, const TrajDesc *d_trajs, int S, int G, int64_t nb, int32_t *d_seg_start,
+                      int32_t *d_seg_state, int32_t *d_traj_id, void *stream)
+{
+    hipLaunchKernelGGL(pair_tasks_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_first_task, n_traj, d_trajs, S, G,
+                       nb, d_seg_start, d_seg_state, d_traj_id);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
 
 size_t device_schedule_bytes(int64_t n)
 {

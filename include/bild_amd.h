@@ -230,13 +230,13 @@ int bild_logl_segments_device(const bild_model *m, const bild_trajset *ts, int64
  * beyond the new state's own sums (16 bytes per entry).  A candidate whose next switch is at least that many frames
  * away takes the entry and runs nothing.  Second level, the pair table: two switches closer together than the first
  * one's transient, keyed by (old, middle, new state, frame, gap <= 64) -- built for trajectory sets where the build (a
- * launch of T x gaps x S(S-1)^2 short tasks per trajectory) needs at most 2 M tasks; chains of three and more close
+ * launch of T x gaps x S(S-1)^2 short tasks per trajectory) needs at most 40 M tasks; chains of three and more close
  * switches are run frame by frame from the table's state in front of them.  All tables are built at the FIRST evaluation
  * on a trajectory set and never later, and whether they are built depends on the set alone: results are reproducible
  * bit for bit for a given trajectory set whatever was evaluated before, in whatever batches and order.  The same candidate
  * evaluated on two different sets (one trajectory alone / among hundreds) may take its sums from different tables and
  * agrees to ~1e-11.  BILD_NO_TRANSIENTS=1 / BILD_NO_PAIRS=1 (environment) switch a level off for experiments;
- * BILD_PAIRS_MAX_TASKS=<n> replaces the 2 M budget (sets of many trajectories that will see hundreds of batches).
+ * BILD_PAIRS_MAX_TASKS=<n> replaces the 40 M budget (sets of many trajectories that will see hundreds of batches).
  *
  * Candidates then differ in length, so the order in which they are dealt to wavefronts matters for speed (never for
  * results).  The host-buffer entry points schedule internally (batches larger than the chip holds at once: on the device,

@@ -628,9 +628,9 @@ def test_baseline_config4_full_samples_per_trajectory(built_lib):
         sl = slice(j * per, (j + 1) * per)
         alone = model.logL_segments(seg_start[sl][::-1], seg_state[sl][::-1], trajs, tid[sl][::-1])[::-1]
         assert np.array_equal(alone, results['auto'][sl])
-    # one trajectory at a time through the sampler seam: a trajectory set of its own, small enough for the pair table
-    # (api.cpp: ensure_pairs) that the set of six does not get -- the pieces of a sum are cut differently, the values agree
-    # to rounding (1e-11 observed), not to the bit
+    # one trajectory at a time through the sampler seam: a trajectory set of its own.  Whether a set gets the pair table
+    # (api.cpp: ensure_pairs) depends on its size; where two sets differ in that, the pieces of a sum are cut differently and
+    # the values agree to rounding (1e-11 observed), not to the bit -- the bar here covers both cases
     for j in (1, 5):
         sl = slice(j * per, (j + 1) * per)
         sampler = bild_amd.FixedkSampler(trajs[j], model, k=k, N=per, max_fcomplete=0)
