@@ -22,6 +22,7 @@ MODEL_NO_REDUCE = 1
 VALIDATE_DEVICE = 0x10
 NO_PREFIX = 0x20
 NO_JUMP = 0x40
+NO_SPLIT = 0x80
 
 Q_N, Q_D, Q_S, Q_MODAL_OK, Q_NP, Q_NEFF, Q_HAS_G = range(7)
 X_LAMBDA, X_SIGMA, X_Q, X_WQ, X_R, X_C0Q, X_V = range(7)
@@ -77,6 +78,8 @@ _SIGNATURES = {
     'bild_flop_count': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, _ip, ctypes.c_uint, _dp, _dp]),
     'bild_kernel_timing': (ctypes.c_int, [ctypes.c_int]),
     'bild_kernel_timing_read': (ctypes.c_int, [_dp, ctypes.POINTER(ctypes.c_int64), ctypes.c_char_p, ctypes.c_int]),
+    'bild_kernel_timing_read_walk': (ctypes.c_int, [_dp, ctypes.POINTER(ctypes.c_int64)]),
+    'bild_logl_st_status': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int64)]),
     # host-side AMIS bookkeeping (amis_host.cpp)
     'bild_amis_create': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _vp, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                         _dp, _dp, ctypes.POINTER(_vp)]),
@@ -232,18 +235,18 @@ class TrajSetHandle:
             self._h = None
 
 
-def logl_segments(model, ts, seg_start, seg_state, traj_id=None, path='auto', prefix=True, jump=True):
+def logl_segments(model, ts, seg_start, seg_state, traj_id=None, path='auto', prefix=True, jump=True, split=True):
     seg_start, seg_state = i32(seg_start), i32(seg_state)
     n, K1 = seg_start.shape
     assert seg_state.shape == (n, K1)
     tid = None if traj_id is None else i32(traj_id)
     out = np.empty(n, dtype=np.float64)
     check(lib().bild_logl_segments(model._h, ts._h, n, K1, iptr(seg_start), iptr(seg_state), iptr(tid),
-                                   _flags(path, prefix=prefix, jump=jump), dptr(out)))
+                                   _flags(path, prefix=prefix, jump=jump, split=split), dptr(out)))
     return out
 
 
-def logl_st(model, ts, ss, thetas, traj_id=None, path='auto', prefix=True, jump=True):
+def logl_st(model, ts, ss, thetas, traj_id=None, path='auto', prefix=True, jump=True, split=True):
     """ the sampler's (s, theta) batch as it is: switch frames are computed natively (bild_logl_st) """
     ss = f64(ss)
     thetas = np.ascontiguousarray(thetas, dtype=np.int64)
@@ -253,7 +256,7 @@ def logl_st(model, ts, ss, thetas, traj_id=None, path='auto', prefix=True, jump=
     assert ss.shape == (n, K1)
     tid = None if traj_id is None else i32(traj_id)
     out = np.empty(n, dtype=np.float64)
-    check(lib().bild_logl_st(model._h, ts._h, n, K1, dptr(ss), thetas.ctypes.data_as(_vp), iptr(tid), _flags(path, prefix=prefix, jump=jump), dptr(out)))
+    check(lib().bild_logl_st(model._h, ts._h, n, K1, dptr(ss), thetas.ctypes.data_as(_vp), iptr(tid), _flags(path, prefix=prefix, jump=jump, split=split), dptr(out)))
     return out
 
 
@@ -292,8 +295,9 @@ def logl_profiles(model, ts, states, traj_id=None, path='auto'):
     return out
 
 
-def _flags(path, validate=False, prefix=True, jump=True):
-    return PATHS[path] | (VALIDATE_DEVICE if validate else 0) | (0 if prefix else NO_PREFIX) | (0 if jump else NO_JUMP)
+def _flags(path, validate=False, prefix=True, jump=True, split=True):
+    return (PATHS[path] | (VALIDATE_DEVICE if validate else 0) | (0 if prefix else NO_PREFIX) | (0 if jump else NO_JUMP) |
+            (0 if split else NO_SPLIT))
 
 
 def frames_run_read(model):
@@ -337,14 +341,14 @@ def prefix_info(ts):
 
 
 def logl_segments_device(model, ts, n, K1, d_seg_start, d_seg_state, d_traj_id, d_out, stream=0, path='auto', validate=False,
-                         d_order=0, prefix=True, jump=True):
+                         d_order=0, prefix=True, jump=True, split=True):
     """
     raw device pointers (ints); asynchronous on `stream` (validate=True: descriptors checked on the device first);
     d_order: device pointer of the launch order from `schedule_segments`, 0 = the order of the arrays
     """
     check(lib().bild_logl_segments_device_ordered(model._h, ts._h, n, K1, _vp(d_seg_start), _vp(d_seg_state),
                                           _vp(d_traj_id) if d_traj_id else None, _vp(d_order) if d_order else None,
-                                          _flags(path, validate, prefix, jump),
+                                          _flags(path, validate, prefix, jump, split),
                                           _vp(stream) if stream else None, _vp(d_out)))
 
 
@@ -364,6 +368,19 @@ def kernel_timing_read():
     name = ctypes.create_string_buffer(128)
     check(lib().bild_kernel_timing_read(ctypes.byref(ms), ctypes.byref(cnt), name, 128))
     return ms.value, cnt.value, name.value.decode()
+
+
+def kernel_timing_read_walk():
+    """ device time and number of launches of the table-walk kernel (walk.hip) since the last call """
+    ms, cnt = ctypes.c_double(0), ctypes.c_int64(0)
+    check(lib().bild_kernel_timing_read_walk(ctypes.byref(ms), ctypes.byref(cnt)))
+    return ms.value, cnt.value
+
+
+def logl_st_status(model):
+    """ waits for the model's pending to_device calls; raises if one of their rows was refused (bild_logl_st_status) """
+    row = ctypes.c_int64(-1)
+    check(lib().bild_logl_st_status(model._h, ctypes.byref(row)))
 
 
 COMM_ID_BYTES = 128

@@ -118,6 +118,7 @@ std::atomic<int32_t *> g_frames_task{nullptr}; // diagnostics: bild_debug_frames
 std::mutex g_time_mu;
 bool g_time_on = false;
 std::vector<std::pair<hipEvent_t, hipEvent_t>> g_time_events;
+std::vector<std::pair<hipEvent_t, hipEvent_t>> g_walk_events; // the table walk in front of a split launch (walk.hip)
 std::string g_time_name;
 
 } // namespace
@@ -161,8 +162,9 @@ struct bild_model {
     mutable PinnedBuf h_in, h_out;
     mutable hipStream_t stream = nullptr;
     mutable unsigned long long *d_frames = nullptr; // frames the tasks ran themselves, summed while kernel timing is on
-    mutable hipEvent_t h_in_event = nullptr; // completion of the last copy out of h_in that nobody waited for
+    mutable hipEvent_t h_in_event = nullptr; // behind the last kernel of a call that left its results on the device (nobody waited)
     mutable bool h_in_busy = false;
+    mutable PinnedBuf h_status; // (s, theta) rows refused on the device by calls nobody waited for: sticky until bild_logl_st_status
 };
 
 struct bild_trajset {
@@ -183,6 +185,7 @@ struct bild_trajset {
     mutable std::mutex prefix_mu;
     mutable std::atomic<int> prefix_state{0};
     mutable double *d_prefix = nullptr;
+    mutable double *d_prefix_L = nullptr; // running log-likelihood of every record, densely (walk.hip reads nothing else)
     mutable int64_t prefix_records = 0;
     mutable double prefix_build_ms = 0.0;
     // transient table (common.h: TransEntry), built right behind the prefix table: 0 not tried, 1 built, -1 none
@@ -617,16 +620,19 @@ int ensure_prefix(const bild_model &m, const bild_trajset &ts, hipStream_t st)
             host[(size_t)2 * nb + (size_t)j * S + s] = j; // traj_id
         }
     int32_t *d_desc = nullptr;
-    double *d_tab = nullptr, *d_sink = nullptr;
+    double *d_tab = nullptr, *d_sink = nullptr, *d_L = nullptr;
     auto cleanup = [&](bool keep) {
         if (d_desc) (void)hipFree(d_desc);
         if (d_sink) (void)hipFree(d_sink);
         if (!keep && d_tab) (void)hipFree(d_tab);
+        if (!keep && d_L) (void)hipFree(d_L);
     };
     hipEvent_t e0 = nullptr, e1 = nullptr;
     bool ok = hipMalloc((void **)&d_desc, host.size() * sizeof(int32_t)) == hipSuccess &&
               hipMalloc((void **)&d_sink, (size_t)nb * ts.dstar_max * sizeof(double)) == hipSuccess &&
               hipMalloc((void **)&d_tab, bytes) == hipSuccess &&
+              hipMalloc((void **)&d_L, (size_t)ts.prefix_records * sizeof(double)) == hipSuccess &&
+              hipMemset(d_L, 0, (size_t)ts.prefix_records * sizeof(double)) == hipSuccess &&
               hipMemcpy(d_desc, host.data(), host.size() * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess &&
               hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
     if (ok) {
@@ -639,6 +645,7 @@ int ensure_prefix(const bild_model &m, const bild_trajset &ts, hipStream_t st)
         p.traj_id = d_desc + 2 * nb;
         p.out = d_sink;
         p.prefix_dump = d_tab;
+        p.prefix_L_dump = d_L;
         const int64_t tpb = (int64_t)geom.W * geom.tasks_per_wave();
         const int grid = (int)std::min<int64_t>(std::max<int64_t>((p.ntasks + tpb - 1) / tpb, 1), 256 * 16);
         (void)hipEventRecord(e0, st);
@@ -653,6 +660,7 @@ int ensure_prefix(const bild_model &m, const bild_trajset &ts, hipStream_t st)
     cleanup(ok);
     if (ok) {
         ts.d_prefix = d_tab;
+        ts.d_prefix_L = d_L;
         ts.prefix_state = 1;
     } else {
         (void)hipGetLastError();
@@ -660,9 +668,23 @@ int ensure_prefix(const bild_model &m, const bild_trajset &ts, hipStream_t st)
     return BILD_OK;
 }
 
+// What a launch may be given beyond the segment lists (all device-visible, all optional)
+struct SplitIn {
+    // the sampler's own (s, theta) instead of segment lists (bild/amis.py:717-739): the walk kernel converts them on
+    // the device and writes the lists the frame loop needs into d_seg_start / d_seg_state of the call (then WRITABLE)
+    const double *d_ss = nullptr;
+    const int8_t *d_thetas = nullptr;
+    int32_t *status = nullptr;   // [0] != 0: a row was not a point on the simplex, [1]: such a row
+    // kWorkBuckets zeroed counters, and kWorkBuckets lists of n * dstar_max task indices each; null: allocated per
+    // call on the stream (re-entrant device entry points)
+    int32_t *d_work = nullptr;
+    int32_t *d_work_lists = nullptr;
+};
 int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1, const int32_t *d_seg_start,
                  const int32_t *d_seg_state, const int32_t *d_traj_id, const int32_t *d_order, unsigned flags,
-                 hipStream_t st, double *d_out);
+                 hipStream_t st, double *d_out, const SplitIn *sp = nullptr);
+// split launches (table walk + frame loop over the work lists) are possible for this many segments per candidate
+constexpr int kSplitMaxK1 = kSegLds;
 
 // The transient table of a trajectory set (common.h: TransEntry), built once behind the prefix table: one ordinary
 // two-segment candidate per (trajectory, old state, new state, switch frame), evaluated by the likelihood kernel in its
@@ -830,7 +852,7 @@ int ensure_pairs(const bild_model &m, const bild_trajset &ts, hipStream_t st)
 
 int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1, const int32_t *d_seg_start,
                  const int32_t *d_seg_state, const int32_t *d_traj_id, const int32_t *d_order, unsigned flags,
-                 hipStream_t st, double *d_out)
+                 hipStream_t st, double *d_out, const SplitIn *sp)
 {
     int mode;
     int rc = pick_mode(m, flags, &mode);
@@ -917,17 +939,101 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
         HIP_TRY(hipMallocAsync((void **)&target, (size_t)p.ntasks * sizeof(double), st));
     }
     p.out = target;
-
-    // tasks per workgroup (the tile kernels size their own grid: 4 waves x 4 tasks)
-    const int64_t tasks_per_block = fam == kWide ? 1 : fam != kVector ? 16 : (int64_t)geom.W * geom.tasks_per_wave();
-    int64_t blocks = (p.ntasks + tasks_per_block - 1) / tasks_per_block;
-    const int grid = (int)std::min<int64_t>(std::max<int64_t>(blocks, 1), 256 * 16);
-    hipEvent_t e0 = nullptr, e1 = nullptr;
     bool timing;
     {
         std::lock_guard<std::mutex> lk(g_time_mu);
         timing = g_time_on;
     }
+
+    // ---- the table walk in front of the frame loop (walk.hip) -----------------------------------------------------
+    // With all tables in place a task is a handful of lookups unless it holds a chain of three or more close switches:
+    // one lane per task walks the tables and writes the result, or hands the task on through the work lists; the frame
+    // loop then runs the listed tasks only.  Same numbers added in the same order: bit-identical to the single launch
+    // (BILD_NO_SPLIT=1).  Also the place where (s, theta) input becomes segment lists.
+    const bool st_in = sp && sp->d_ss;
+    if (st_in && K1 > kSplitMaxK1) return fail(BILD_ERR_INVALID, "internal: (s, theta) input with %d segments", K1);
+    static const bool no_split_env = getenv("BILD_NO_SPLIT") != nullptr;
+    const bool no_split = no_split_env || (flags & BILD_NO_SPLIT);
+    const bool split = fam == kVector && mode == kModal && K1 <= kSplitMaxK1 && !tl_building && !no_split && p.trans != nullptr &&
+                       p.walk_lds && ts.d_prefix_L != nullptr && p.ntasks <= (int64_t)INT_MAX;
+    int32_t *work_alloc = nullptr;
+    auto release = [&]() {
+        if (ts.dstar_max > 1) (void)hipFreeAsync(target, st);
+        if (work_alloc) (void)hipFreeAsync(work_alloc, st);
+    };
+    if (split || st_in) {
+        WalkParams w{};
+        w.trajs = ts.d_descs;
+        w.S = m.S;
+        w.dstar_max = ts.dstar_max;
+        w.K1 = K1;
+        w.n = n;
+        w.traj_id = d_traj_id;
+        if (st_in) {
+            w.ss = sp->d_ss;
+            w.thetas = sp->d_thetas;
+            w.seg_out_start = const_cast<int32_t *>(d_seg_start);
+            w.seg_out_state = const_cast<int32_t *>(d_seg_state);
+            w.status = sp->status;
+        } else {
+            w.seg_start = d_seg_start;
+            w.seg_state = d_seg_state;
+        }
+        w.convert_all = split ? 0 : 1;
+        if (split) {
+            int32_t *d_work = sp ? sp->d_work : nullptr, *d_lists = sp ? sp->d_work_lists : nullptr;
+            if (!d_work || !d_lists) {
+                const size_t bytes = ((size_t)kWorkBuckets + (size_t)kWorkBuckets * (size_t)p.ntasks) * sizeof(int32_t);
+                hipError_t he = hipMallocAsync((void **)&work_alloc, bytes, st);
+                if (he == hipSuccess) he = hipMemsetAsync(work_alloc, 0, kWorkBuckets * sizeof(int32_t), st);
+                if (he != hipSuccess) {
+                    release();
+                    return fail(BILD_ERR_NOMEM, "work lists: %s", hipGetErrorString(he));
+                }
+                d_work = work_alloc;
+                d_lists = work_alloc + kWorkBuckets;
+            }
+            w.Lc = ts.d_prefix_L;
+            w.trans = p.trans;
+            w.trans2 = p.trans2;
+            w.gap_max = p.gap_max;
+            w.m_typ = p.m_typ;
+            w.out = target;
+            w.work_counts = d_work;
+            w.work = d_lists;
+            w.work_cap = p.ntasks;
+            w.frames_task = p.frames_task;
+            p.work_counts = w.work_counts;
+            p.work = w.work;
+            p.work_cap = w.work_cap;
+            p.order = nullptr; // the work lists ARE the launch order
+        }
+        hipEvent_t w0 = nullptr, w1 = nullptr;
+        if (timing) {
+            HIP_TRY(hipEventCreate(&w0));
+            HIP_TRY(hipEventCreate(&w1));
+            HIP_TRY(hipEventRecord(w0, st));
+        }
+        const int wrc = launch_walk(w, (void *)st);
+        if (wrc != 0) {
+            release();
+            return fail(BILD_ERR_HIP, "walk kernel launch failed: %s", hipGetErrorString((hipError_t)wrc));
+        }
+        if (timing) {
+            HIP_TRY(hipEventRecord(w1, st));
+            std::lock_guard<std::mutex> lk(g_time_mu);
+            g_walk_events.emplace_back(w0, w1);
+        }
+    }
+
+    // tasks per workgroup (the tile kernels size their own grid: 4 waves x 4 tasks)
+    const int64_t tasks_per_block = fam == kWide ? 1 : fam != kVector ? 16 : (int64_t)geom.W * geom.tasks_per_wave();
+    int64_t blocks = (p.ntasks + tasks_per_block - 1) / tasks_per_block;
+    // (work lists: one residency of the chip at most -- most of the tasks never reach the frame loop)
+    static const int work_blocks = getenv("BILD_WORK_BLOCKS") ? atoi(getenv("BILD_WORK_BLOCKS")) : 0;
+    const int64_t max_blocks = split ? (work_blocks > 0 ? work_blocks : 256 * std::max(geom.OCC, 1)) : 256 * 16;
+    const int grid = (int)std::min<int64_t>(std::max<int64_t>(blocks, 1), max_blocks);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
     if (timing) {
         HIP_TRY(hipEventCreate(&e0));
         HIP_TRY(hipEventCreate(&e1));
@@ -938,9 +1044,10 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
               : fam == kDenseTiles ? launch_logl_dense_mfma(m.NPm[kDense], p, (void *)st)
                                    : launch_logl(geom, mode, p, grid, lds, (void *)st);
     if (lrc != 0) {
-        if (ts.dstar_max > 1) (void)hipFreeAsync(target, st);
+        release();
         return fail(BILD_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
     }
+    if (work_alloc) (void)hipFreeAsync(work_alloc, st);
     if (timing) {
         HIP_TRY(hipEventRecord(e1, st));
         std::lock_guard<std::mutex> lk(g_time_mu);
@@ -1020,6 +1127,7 @@ bool schedule(const bild_model &m, const bild_trajset &ts, int64_t n, int K1, co
             if (run_from >= 0 && !(links == 1 || (pairs && links == 2))) w += T - run_from;
             w = w > Tmax ? Tmax : w;
         }
+        w = w < 0 ? 0 : w; // (a row of decreasing starts can make the estimate negative; host entries reject such rows beforehand)
         work[r] = w;
         ++count[Tmax - w + 1];
     }
@@ -1108,6 +1216,8 @@ int device_order(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
     if (path != BILD_PATH_AUTO && path != BILD_PATH_MODAL) return 1;
     if ((flags & (BILD_NO_PREFIX | BILD_NO_JUMP)) || getenv("BILD_NO_PREFIX") || getenv("BILD_NO_JUMP") || getenv("BILD_NO_SCHEDULE")) return 1;
     if (ts.prefix_state != 1 || ts.trans_state != 1) return 1;
+    // a split launch orders its frame loop itself (work lists by expected work)
+    if (K1 <= kSplitMaxK1 && !getenv("BILD_NO_SPLIT")) return 1;
     Geometry geom{};
     if (!geometry_for(m.NPm[kModal], kModal, n * ts.dstar_max, ts.means_max, &geom)) return 1;
     if (geom.tasks_per_wave() % ts.dstar_max != 0) return 1;
@@ -1142,9 +1252,20 @@ struct StageClock {
     }
 };
 
+// Device block of a host-buffer call (ws_in), filled by ONE copy out of the pinned block of the same layout:
+//   [ header: kWorkBuckets work-list counters, zero | status word, bad row, padding ]        kStagedHeader bytes
+//   [ payload: segment lists (seg_start | seg_state), or (s, theta) rows (ss float64 | thetas uint8, padded to 8 bytes) ]
+//   [ traj_id (n int32), when given ] [ launch order (n int32), when the host scheduled ]
+// and behind what is copied, device only:
+//   [ (s, theta) input: the segment lists the walk kernel writes for the frame loop: seg_start | seg_state ]
+//   [ work lists: kWorkBuckets x (n * dstar_max) int32 ]
+// The zero header travels with the payload, so the counters need no memset of their own.
+constexpr size_t kStagedHeader = 128;
+static_assert(kStagedHeader >= (kWorkBuckets + 2) * sizeof(int32_t), "header holds the counters and the status");
+
 template <typename Fill>
 int run_staged(const bild_model *m, const bild_trajset *ts, int64_t n, int K1, const int32_t *traj_id, unsigned flags,
-               double *out, double *d_out_user, hipStream_t st_user, Fill &&fill)
+               double *out, double *d_out_user, hipStream_t st_user, bool st_payload, Fill &&fill)
 {
     int rc;
     if (traj_id)
@@ -1153,51 +1274,90 @@ int run_staged(const bild_model *m, const bild_trajset *ts, int64_t n, int K1, c
                 return fail(BILD_ERR_INVALID, "traj_id[%lld]=%d out of range", (long long)r, traj_id[r]);
     std::lock_guard<std::mutex> call_lock(m->call_mu);
     const size_t nseg = (size_t)n * K1;
-    const size_t in_cap = (2 * nseg + 2 * (size_t)n) * sizeof(int32_t); // room for traj_id and the launch order
-    // a previous call that left its results on the device may still be reading the staging block
+    const size_t ntasks = (size_t)n * ts->dstar_max;
+    const size_t payload = st_payload ? nseg * sizeof(double) + ((nseg + 7) & ~(size_t)7) : 2 * nseg * sizeof(int32_t);
+    const size_t copy_cap = kStagedHeader + payload + 2 * (size_t)n * sizeof(int32_t); // room for traj_id and the launch order
+    const size_t lists = st_payload ? 2 * nseg * sizeof(int32_t) : 0;
+    const size_t work = K1 <= kSplitMaxK1 ? (size_t)kWorkBuckets * ntasks * sizeof(int32_t) : 0;
+    // A previous call that left its results on the device (bild_logl_st_to_device: nothing waited for) may still be
+    // running: its kernels read the device block and the work lists, its copy reads the pinned block.  The event was
+    // recorded behind its last kernel.
     if (m->h_in_busy) HIP_TRY(hipEventSynchronize(m->h_in_event));
     m->h_in_busy = false;
     {
         std::lock_guard<std::mutex> lk(m->mu);
-        if ((rc = m->h_in.reserve(in_cap))) return rc;
-        if ((rc = m->ws_in.reserve(in_cap))) return rc;
-        if (!d_out_user) {
-            if ((rc = m->h_out.reserve((size_t)n * sizeof(double)))) return rc;
-            if ((rc = m->ws_out.reserve((size_t)n * sizeof(double)))) return rc;
-        }
+        if ((rc = m->h_in.reserve(copy_cap))) return rc;
+        if ((rc = m->ws_in.reserve(copy_cap + lists + work))) return rc;
+        if ((rc = m->h_out.reserve((size_t)n * sizeof(double) + 64))) return rc; // (+ the status word of (s, theta) input)
+        if (!d_out_user && (rc = m->ws_out.reserve((size_t)n * sizeof(double)))) return rc;
     }
     StageClock clk;
-    int32_t *h_start = (int32_t *)m->h_in.ptr, *h_state = h_start + nseg, *h_tid = h_state + nseg;
+    char *h_base = (char *)m->h_in.ptr, *d_base = (char *)m->ws_in.ptr;
+    std::memset(h_base, 0, kStagedHeader);
+    int32_t *h_tid = (int32_t *)(h_base + kStagedHeader + payload);
     int32_t *h_order = h_tid + (traj_id ? n : 0);
-    if ((rc = fill(h_start, h_state))) return rc;
+    if ((rc = fill(h_base + kStagedHeader))) return rc;
     if (traj_id) std::memcpy(h_tid, traj_id, (size_t)n * sizeof(int32_t));
     clk.lap(0);
-    const bool ordered = schedule(*m, *ts, n, K1, h_start, h_state, traj_id, flags, h_order, true);
+    // the host scheduler serves launches that will NOT be split (no tables, BILD_NO_JUMP, ...): see schedule()
+    const bool ordered = !st_payload && schedule(*m, *ts, n, K1, (const int32_t *)(h_base + kStagedHeader),
+                                                 (const int32_t *)(h_base + kStagedHeader) + nseg, traj_id, flags, h_order, true);
     clk.lap(1);
-    const size_t in_bytes = (2 * nseg + (traj_id ? (size_t)n : 0) + (ordered ? (size_t)n : 0)) * sizeof(int32_t);
-    int32_t *d_start = (int32_t *)m->ws_in.ptr, *d_state = d_start + nseg, *d_tid = traj_id ? d_state + nseg : nullptr;
-    const int32_t *d_order = ordered ? d_state + nseg + (traj_id ? n : 0) : nullptr;
+    const size_t in_bytes = kStagedHeader + payload + ((traj_id ? (size_t)n : 0) + (ordered ? (size_t)n : 0)) * sizeof(int32_t);
+    int32_t *d_tid = traj_id ? (int32_t *)(d_base + kStagedHeader + payload) : nullptr;
+    const int32_t *d_order = ordered ? (int32_t *)(d_base + kStagedHeader + payload) + (traj_id ? n : 0) : nullptr;
+    int32_t *d_start, *d_state;
+    SplitIn sp;
+    // the status word lives in pinned host memory the device writes to directly: the host reads it after its synchronisation
+    int32_t *h_status = (int32_t *)((char *)m->h_out.ptr + (size_t)n * sizeof(double));
+    if (st_payload) {
+        d_start = (int32_t *)(d_base + copy_cap);
+        d_state = d_start + nseg;
+        sp.d_ss = (const double *)(d_base + kStagedHeader);
+        sp.d_thetas = (const int8_t *)(d_base + kStagedHeader + nseg * sizeof(double));
+        if (d_out_user) { // nobody waits: the verdict stays with the model until bild_logl_st_status asks
+            if (!m->h_status.ptr) {
+                std::lock_guard<std::mutex> lk(m->mu);
+                if ((rc = m->h_status.reserve(64))) return rc;
+                std::memset(m->h_status.ptr, 0, 64);
+            }
+            h_status = (int32_t *)m->h_status.ptr;
+        } else {
+            h_status[0] = h_status[1] = 0;
+        }
+        sp.status = h_status;
+    } else {
+        d_start = (int32_t *)(d_base + kStagedHeader);
+        d_state = d_start + nseg;
+    }
+    if (work) {
+        sp.d_work = (int32_t *)d_base; // the zero header
+        sp.d_work_lists = (int32_t *)(d_base + copy_cap + lists);
+    }
     double *d_out = d_out_user ? d_out_user : (double *)m->ws_out.ptr;
     hipStream_t st = d_out_user ? st_user : m->stream;
-    HIP_TRY(hipMemcpyAsync(d_start, h_start, in_bytes, hipMemcpyHostToDevice, st));
-    if (d_out_user) {
-        HIP_TRY(hipEventRecord(m->h_in_event, st));
-        m->h_in_busy = true;
-    }
-    if (!ordered) {
+    HIP_TRY(hipMemcpyAsync(d_base, h_base, in_bytes, hipMemcpyHostToDevice, st));
+    if (!ordered && !st_payload) {
         const int32_t *on_device = nullptr;
         if (device_order(*m, *ts, n, K1, d_start, d_tid, flags, st, &on_device) == 0) d_order = on_device;
     }
-    rc = launch_batch(*m, *ts, n, K1, d_start, d_state, d_tid, d_order, flags, st, d_out);
+    rc = launch_batch(*m, *ts, n, K1, d_start, d_state, d_tid, d_order, flags, st, d_out, &sp);
     if (rc) {
         (void)hipStreamSynchronize(st);
         return rc;
     }
-    if (d_out_user) return BILD_OK; // results stay in HBM, ordered on the caller's stream
+    if (d_out_user) {
+        // results stay in HBM, ordered on the caller's stream; the event covers everything this call reads
+        HIP_TRY(hipEventRecord(m->h_in_event, st));
+        m->h_in_busy = true;
+        return BILD_OK;
+    }
     clk.lap(2);
     HIP_TRY(hipMemcpyAsync(m->h_out.ptr, d_out, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     clk.lap(3);
+    if (st_payload && h_status[0] != 0)
+        return fail(BILD_ERR_INVALID, "interval lengths of sample %d are not non-negative finite numbers (of a point on the simplex)", h_status[1]);
     std::memcpy(out, m->h_out.ptr, (size_t)n * sizeof(double));
     clk.lap(4);
     if (clk.on) {
@@ -1272,13 +1432,14 @@ int bild_model_destroy(bild_model *m)
         if (m->d_states[mode]) (void)hipFree(m->d_states[mode]);
         if (m->d_tab[mode]) (void)hipFree(m->d_tab[mode]);
     }
+    if (m->h_in_busy) (void)hipEventSynchronize(m->h_in_event); // (a call nobody waited for still reads these blocks)
+    if (m->h_in_event) (void)hipEventDestroy(m->h_in_event);
     m->ws_in.release();
     m->ws_out.release();
     m->ws_sched.release();
     m->h_in.release();
     m->h_out.release();
-    if (m->h_in_busy) (void)hipEventSynchronize(m->h_in_event);
-    if (m->h_in_event) (void)hipEventDestroy(m->h_in_event);
+    m->h_status.release();
     if (m->d_frames) (void)hipFree(m->d_frames);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
@@ -1447,6 +1608,7 @@ int bild_trajset_destroy(bild_trajset *ts)
     if (ts->d_x) (void)hipFree(ts->d_x);
     if (ts->d_descs) (void)hipFree(ts->d_descs);
     if (ts->d_prefix) (void)hipFree(ts->d_prefix);
+    if (ts->d_prefix_L) (void)hipFree(ts->d_prefix_L);
     if (ts->d_trans) (void)hipFree(ts->d_trans);
     if (ts->d_trans2) (void)hipFree(ts->d_trans2);
     delete ts;
@@ -1512,6 +1674,18 @@ int bild_schedule_segments(const bild_model *m, const bild_trajset *ts, int64_t 
     if (traj_id)
         for (int64_t r = 0; r < n; ++r)
             if (traj_id[r] < 0 || traj_id[r] >= ts->n_traj) return fail(BILD_ERR_INVALID, "traj_id out of range");
+    // the same checks as bild_logl_segments: the estimate of a candidate's work indexes arrays with these numbers
+    for (int64_t r = 0; r < n; ++r) {
+        const int32_t *a = seg_start + r * K1;
+        if (a[0] != 0) return fail(BILD_ERR_INVALID, "seg_start[%lld][0] must be 0", (long long)r);
+        for (int i = 1; i < K1; ++i)
+            if (a[i] < a[i - 1] || a[i] < 1)
+                return fail(BILD_ERR_INVALID, "segment starts of sample %lld are decreasing (or a later segment starts at frame 0)", (long long)r);
+        if (seg_state)
+            for (int i = 0; i < K1; ++i)
+                if (seg_state[r * K1 + i] < 0 || seg_state[r * K1 + i] >= m->S)
+                    return fail(BILD_ERR_INVALID, "state %d out of range at sample %lld", seg_state[r * K1 + i], (long long)r);
+    }
     if (!schedule(*m, *ts, n, K1, seg_start, seg_state, traj_id, flags, order, false))
         for (int64_t r = 0; r < n; ++r) order[r] = (int32_t)r;
     return BILD_OK;
@@ -1597,7 +1771,8 @@ int bild_logl_segments(const bild_model *m, const bild_trajset *ts, int64_t n, i
     if (n == 0) return BILD_OK;
     if (!seg_start || !seg_state || !out) return fail(BILD_ERR_INVALID, "NULL buffer");
     const int S = m->S;
-    return run_staged(m, ts, n, K1, traj_id, flags, out, nullptr, nullptr, [&](int32_t *h_start, int32_t *h_state) -> int {
+    return run_staged(m, ts, n, K1, traj_id, flags, out, nullptr, nullptr, false, [&](char *payload) -> int {
+        int32_t *h_start = (int32_t *)payload, *h_state = h_start + (size_t)n * K1;
         for (int64_t r = 0; r < n; ++r) {
             const int32_t *a = seg_start + r * K1, *b = seg_state + r * K1;
             if (a[0] != 0) return fail(BILD_ERR_INVALID, "seg_start[%lld][0] must be 0", (long long)r);
@@ -1671,7 +1846,28 @@ static int logl_st_impl(const bild_model *m, const bild_trajset *ts, int64_t n, 
     if (n == 0) return BILD_OK;
     if (!ss || !thetas || (!out && !d_out)) return fail(BILD_ERR_INVALID, "NULL buffer");
     const int S = m->S;
-    return run_staged(m, ts, n, K1, traj_id, flags, out, d_out, (hipStream_t)hip_stream, [&](int32_t *h_start, int32_t *h_state) -> int {
+    // The rows go up as they are -- float64 interval lengths, states narrowed to one byte -- and the walk kernel turns
+    // them into switch frames on the device (walk.hip; same operations as st_row below, bit for bit).  Lists of more
+    // segments than that kernel holds in registers are converted here.
+    static const bool host_convert = getenv("BILD_ST_ON_HOST") != nullptr;
+    if (K1 <= kSplitMaxK1 && !host_convert)
+        return run_staged(m, ts, n, K1, traj_id, flags, out, d_out, (hipStream_t)hip_stream, true, [&](char *payload) -> int {
+            const size_t nseg = (size_t)n * K1;
+            std::memcpy(payload, ss, nseg * sizeof(double));
+            uint8_t *th8 = (uint8_t *)(payload + nseg * sizeof(double));
+            uint64_t bad = 0;
+            for (size_t i = 0; i < nseg; ++i) {
+                bad |= (uint64_t)((uint64_t)thetas[i] >= (uint64_t)S);
+                th8[i] = (uint8_t)thetas[i];
+            }
+            if (bad)
+                for (size_t i = 0; i < nseg; ++i)
+                    if (thetas[i] < 0 || thetas[i] >= S)
+                        return fail(BILD_ERR_INVALID, "state %lld out of range at sample %lld", (long long)thetas[i], (long long)(i / K1));
+            return BILD_OK;
+        });
+    return run_staged(m, ts, n, K1, traj_id, flags, out, d_out, (hipStream_t)hip_stream, false, [&](char *payload) -> int {
+        int32_t *h_start = (int32_t *)payload, *h_state = h_start + (size_t)n * K1;
         for (int64_t r = 0; r < n; ++r) {
             const double Tm1 = (double)(ts->descs[traj_id ? traj_id[r] : 0].T - 1);
             int rc2 = st_row(ss + r * K1, thetas + r * K1, K1, S, Tm1, r, h_start + r * K1, h_state + r * K1);
@@ -1758,6 +1954,44 @@ int bild_flop_count(const bild_model *m, const bild_trajset *ts, int64_t n, cons
     }
     *canonical = can;
     *executed = exe;
+    return BILD_OK;
+}
+
+int bild_logl_st_status(const bild_model *m, int64_t *bad_row)
+{
+    if (!m) return fail(BILD_ERR_INVALID, "NULL handle");
+    std::lock_guard<std::mutex> call_lock(m->call_mu);
+    if (m->h_in_busy) HIP_TRY(hipEventSynchronize(m->h_in_event));
+    m->h_in_busy = false;
+    if (bad_row) *bad_row = -1;
+    if (!m->h_status.ptr) return BILD_OK;
+    int32_t *h = (int32_t *)m->h_status.ptr;
+    if (h[0] == 0) return BILD_OK;
+    const int row = h[1];
+    h[0] = h[1] = 0;
+    if (bad_row) *bad_row = row;
+    return fail(BILD_ERR_INVALID, "interval lengths of sample %d are not non-negative finite numbers (of a point on the simplex)", row);
+}
+
+int bild_kernel_timing_read_walk(double *total_ms, int64_t *launches)
+{
+    if (!total_ms || !launches) return fail(BILD_ERR_INVALID, "NULL argument");
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    {
+        std::lock_guard<std::mutex> lk(g_time_mu);
+        ev.swap(g_walk_events);
+    }
+    double tot = 0.0;
+    for (auto &pr : ev) {
+        HIP_TRY(hipEventSynchronize(pr.second));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
+        tot += ms;
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    *total_ms = tot;
+    *launches = (int64_t)ev.size();
     return BILD_OK;
 }
 

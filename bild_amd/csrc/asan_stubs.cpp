@@ -28,6 +28,7 @@ int launch_pair_tasks(const int64_t *, int, const TrajDesc *, int, int, int64_t,
 size_t device_schedule_bytes(int64_t) { return 0; }
 int device_schedule(const int32_t *, const int32_t *, const TrajDesc *, int, int64_t, int, int, int, int, int64_t, void *, size_t, const int32_t **, void *) { return 1; }
 int launch_logl_wide(int, const KParams &, int, void *) { return 1; }
+int launch_walk(const WalkParams &, void *) { return 1; }
 int amis_dev_pass_a_rows(int64_t, int64_t) { return 0; }
 int amis_dev_pass_a(const AmisView &, int64_t, int64_t, int64_t, double, double *, double *, double *, double *, double *, int *) { return 1; }
 int amis_dev_pass_b(const AmisView &, int64_t, double, int, const double *, double *, double *, int) { return 1; }

@@ -57,7 +57,8 @@ bool load_rccl()
     for (const char *c : candidates)
         if (!h && c) h = dlopen(c, RTLD_NOW | RTLD_GLOBAL);
     if (!h) {
-        g_rccl.why = std::string("librccl.so not found: ") + (dlerror() ? dlerror() : "?");
+        const char *e = dlerror(); // ONE call: dlerror() clears the state it returns
+        g_rccl.why = std::string("librccl.so not found: ") + (e ? e : "?");
         return false;
     }
     g_rccl.GetUniqueId = (int (*)(ncclUniqueId *))dlsym(h, "ncclGetUniqueId");

@@ -106,7 +106,49 @@ struct KParams {
     TransEntry *trans2_dump;  // non-null: this launch BUILDS the pair table (one task per entry, K1 = 3)
     int32_t gap_max;          // gaps 1 .. gap_max - 1 have entries in the pair table
     int32_t walk_lds;         // the launch has kWalkDoubles of LDS per task behind the segment lists (see logl_kernel: walk plan)
+    double *prefix_L_dump;    // with prefix_dump: the running log-likelihood of every record once more, densely (8 B per record)
+    // work lists (walk.hip): this launch runs only the tasks the table walk could not finish -- kWorkBuckets lists of
+    // `work_cap` task indices (index into `out`) each, heaviest bucket last, with their lengths in work_counts
+    const int32_t *work;
+    const int32_t *work_counts;
+    int64_t work_cap;
 };
+
+// Work lists between the table walk (walk.hip) and the frame loop (kernels.hip).  A task lands in the bucket of the
+// frames it is expected to run (estimate / kWorkBucketFrames, capped): the frame-loop launch deals the buckets out
+// heaviest first -- a counting sort that costs nothing.
+constexpr int kWorkBuckets = 16;
+constexpr int kWorkBucketFrames = 20;
+
+struct WalkParams {
+    const TrajDesc *trajs;
+    int32_t S, dstar_max, K1;
+    int64_t n; // candidates; tasks = n * dstar_max, task = candidate * dstar_max + chain
+    // the candidates: run-length segments (seg_start / seg_state, n x K1) ...
+    const int32_t *seg_start;
+    const int32_t *seg_state;
+    // ... or the sampler's own (s, theta) (bild/amis.py:717-739): ss n x K1 float64, thetas n x K1 int8.  The switch
+    // frames are computed here as FixedkSampler.st2profile does (amis.py:685-688) and the lists of the tasks that go on
+    // to the frame loop (all lists with `convert_all`) are written to seg_out_start / seg_out_state (n x K1).
+    const double *ss;
+    const int8_t *thetas;
+    int32_t *seg_out_start;
+    int32_t *seg_out_state;
+    int32_t convert_all; // no tables to walk: convert every list, finish nothing
+    int32_t *status;     // (s, theta) input: [0] != 0 when a row is not a point on the simplex / a state is out of range, [1] such a row
+    const int32_t *traj_id; // may be null
+    const double *Lc;       // running log-likelihood of the switch-free filters, one double per prefix record
+    const TransEntry *trans;
+    const TransEntry *trans2; // may be null
+    int32_t gap_max, m_typ;
+    double *out;            // results of the tasks that need no frame
+    int32_t *work;          // kWorkBuckets x work_cap
+    int32_t *work_counts;   // kWorkBuckets, zeroed by the caller
+    int64_t work_cap;
+    unsigned long long *tasks_done; // non-null (bench accounting): tasks finished by the walk
+    int32_t *frames_task;           // non-null (diagnostics): a task finished here ran no frame
+};
+int launch_walk(const WalkParams &p, void *stream);
 
 // launch geometry for a padded chain length
 struct Geometry {

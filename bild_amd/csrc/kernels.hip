@@ -205,6 +205,20 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
     const int grp = BLK ? ((lane >> 2) & 3) : lane / G;
     const int gl = BLK ? ((lane & 3) | ((lane >> 4) << 2)) : lane - grp * G; // ROW: lane / 16, lane % 16
 
+    // Work lists (walk.hip): this launch runs only the tasks the table walk handed on -- kWorkBuckets lists by expected
+    // work, dealt out heaviest first.  Slot q of that order goes to (wave, row) so that the heaviest tasks get a wave
+    // each while they fit (the other rows of the wave then idle: a row's events -- basis change, comparison, jump --
+    // are paid by the whole wave), the next heaviest the second rows, and so on; lists longer than the grid has rows
+    // are throughput-bound and tasks of similar work share a wave.
+    const bool listed = JUMP && p.work != nullptr;
+    int64_t n_tasks = p.ntasks;
+    if (listed) {
+        int64_t tot = 0;
+        for (int bq = 0; bq < kWorkBuckets; ++bq) tot += p.work_counts[bq];
+        n_tasks = tot;
+        if ((int64_t)blockIdx.x * kWaves >= tot) return; // (all rows of this workgroup would idle)
+    }
+
     // Matrix tables live in LDS for the whole kernel: the dense propagators are needed every frame,
     // and a modal basis change walks its matrix row by row in a dependent loop -- from L2 that was
     // ~500 cycles per row, 10 us per switch (measured: +89 % kernel time at k = 20).
@@ -244,12 +258,31 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
     const int d = p.d;
     const int K1 = p.K1;
     const int64_t gstride = (int64_t)gridDim.x * (kWaves * GPW);
+    const int64_t n_waves = (int64_t)gridDim.x * kWaves, wave_id = (int64_t)blockIdx.x * kWaves + wv;
+    // (listed, and the list fits the rows of the grid: spread -- row j of wave w takes slot j * n_waves + w)
+    const int64_t first_task = (listed && n_tasks <= gstride) ? (int64_t)grp * n_waves + wave_id : wave_id * GPW + grp;
 
-    for (int64_t task = ((int64_t)blockIdx.x * kWaves + wv) * GPW + grp; task < p.ntasks; task += gstride) {
-        const int64_t slot = task / p.dstar_max;
-        const int e = (int)(task - slot * p.dstar_max);
-        const int64_t r = p.order ? p.order[slot] : slot; // launch order is a scheduling matter only
-        const int64_t otask = r * p.dstar_max + e;
+    for (int64_t task = first_task; task < n_tasks; task += gstride) {
+        int64_t r, otask;
+        int e;
+        if (listed) {
+            // slot `task` of the buckets laid end to end, heaviest (last) bucket first
+            int64_t q = task;
+            int bq = kWorkBuckets - 1;
+            for (; bq > 0; --bq) {
+                const int c = p.work_counts[bq];
+                if (q < c) break;
+                q -= c;
+            }
+            otask = p.work[(int64_t)bq * p.work_cap + q];
+            r = otask / p.dstar_max;
+            e = (int)(otask - r * p.dstar_max);
+        } else {
+            const int64_t slot = task / p.dstar_max;
+            e = (int)(task - slot * p.dstar_max);
+            r = p.order ? p.order[slot] : slot; // launch order is a scheduling matter only
+            otask = r * p.dstar_max + e;
+        }
 #ifdef BILD_TASK_CLOCK
         const unsigned long long clock_begin = wall_clock64(); // diagnostics build only: tools/task_clock.py
         unsigned long long clock_events = 0;                   // (== 2: ticks inside comparisons / jumps, and how many)
@@ -875,6 +908,8 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
                 rec[kRecE] = (double)E;
                 rec[kRecL] = Lsofar;
                 rec[kRecNv] = (double)nv;
+                // ... and once more, densely: the table walk (walk.hip) reads nothing else of a record
+                if (p.prefix_L_dump) p.prefix_L_dump[td->prefix_rec0 + ((int64_t)e * S + s) * T + tt] = Lsofar;
             }
         };
         if constexpr (DUMP) dump(0);

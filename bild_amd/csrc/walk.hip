@@ -1,0 +1,282 @@
+// Table walk: the part of an AMIS batch that needs no Kalman frame (gfx950).
+//
+// With the tables of a trajectory set in place (common.h: prefix / transient / pair table) most candidates of a batch
+// -- 96 % of the headline batch -- are a handful of table lookups: the running log-likelihood of the switch-free
+// filter up to the first switch, then one transient (or pair) entry plus a difference of running sums per switch
+// (reference: the loop bild/amis.py:735-739 over MSRouse_logL, bild/src/MSRouse_logL.pyx:95-256, of which this is an
+// exact-to-rounding restatement).  That arithmetic needs no filter state, so it does not belong
+// on a 16-lane row of the frame-loop kernel (84 registers per lane, LDS tables, spills): here ONE LANE takes one task
+//
+//   * reads its segment list -- or the sampler's own (s, theta) row, which it converts to switch frames exactly as
+//     FixedkSampler.st2profile does (bild/amis.py:685-688: sequential cumsum, one multiplication by T - 1, floor, + 1;
+//     no contraction) --,
+//   * cleans it (kernels.hip: boundaries that switch nothing, empty segments and segments beyond the trajectory go),
+//   * fetches, for all switches at once, the entries the walk may need (independent loads: one round trip),
+//   * walks from synchronised point to synchronised point adding the same numbers in the same order as the frame-loop
+//     kernel's `land`, and
+//   * either writes the result, or -- at the first chain of switches the tables do not cover -- appends the task to
+//     a work list for the frame-loop kernel, which runs only those (kernels.hip, KParams::work).
+//
+// Everything is kept in registers: the lists are indexed with compile-time constants only (loops over KMAX slots,
+// fully unrolled), so nothing goes to scratch memory.  Results are bit-identical to the single-kernel launch
+// (BILD_NO_SPLIT) for every task -- those finished here by construction of the walk, the others because the frame-loop
+// kernel starts them from scratch.
+#include <hip/hip_runtime.h>
+#include <limits.h>
+
+#include "common.h"
+
+namespace bild {
+namespace {
+
+template <int KMAX, bool ST>
+__global__ void __launch_bounds__(64) walk_kernel(const WalkParams p)
+{
+    const int64_t task = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (task >= p.n * p.dstar_max) return;
+    const int64_t r = task / p.dstar_max;
+    const int e = (int)(task - r * p.dstar_max);
+    const int K1 = p.K1, S = p.S;
+    const int tj = p.traj_id ? p.traj_id[r] : 0;
+    const TrajDesc *__restrict__ td = p.trajs + tj;
+    const int T = td->T;
+
+    // ---- the segment list -----------------------------------------------------------------------------------------
+    int a[KMAX], b[KMAX];
+    bool ok = true;
+    if constexpr (ST) {
+        const double *__restrict__ s = p.ss + r * K1;
+        const uint8_t *__restrict__ th = reinterpret_cast<const uint8_t *>(p.thetas) + r * K1;
+        const double Tm1 = (double)(T - 1);
+        double acc = 0.0;
+        int prev = 0;
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i) {
+            a[i] = INT_MAX;
+            b[i] = 0;
+            if (i < K1) {
+                const int st = th[i];
+                ok = ok && st < S;
+                b[i] = st;
+                if (i == 0) a[0] = 0;
+                if (i + 1 < K1) {
+                    acc = __dadd_rn(acc, s[i]);            // np.cumsum: sequential
+                    const double pos = __dmul_rn(acc, Tm1); // one multiplication, not fused with the sum
+                    // floor for 0 <= pos < 2^31 is the truncating conversion; the host's range test (api.cpp: st_row)
+                    // accepts -1 < pos (which truncates to 0) and rejects NaN
+                    const bool in_range = pos > -1.0 && pos < 2147483646.0;
+                    const int idx = in_range ? (int)pos + 1 : INT_MAX;
+                    ok = ok && in_range && idx >= prev;
+                    prev = idx;
+                    if (i + 1 < KMAX) a[i + 1] = idx;
+                }
+            }
+        }
+        if (!ok) {
+            // not a point on the simplex (or a state out of range): nothing of this row drives an address
+            if (atomicCAS(p.status, 0, 1) == 0) p.status[1] = (int)(r < INT_MAX ? r : INT_MAX);
+            if (!p.convert_all) p.out[task] = __longlong_as_double(0x7ff8000000000000ll);
+            return;
+        }
+    } else {
+        const int32_t *__restrict__ sst = p.seg_start + r * K1;
+        const int32_t *__restrict__ ssv = p.seg_state + r * K1;
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i) {
+            a[i] = INT_MAX;
+            b[i] = 0;
+            if (i < K1) {
+                a[i] = sst[i];
+                b[i] = ssv[i];
+            }
+        }
+    }
+    auto write_list = [&]() {
+        if constexpr (ST) {
+            if (e == 0) {
+#pragma unroll
+                for (int i = 0; i < KMAX; ++i)
+                    if (i < K1) {
+                        p.seg_out_start[r * K1 + i] = a[i];
+                        p.seg_out_state[r * K1 + i] = b[i];
+                    }
+            }
+        }
+    };
+    if (p.convert_all) {
+        write_list();
+        return;
+    }
+    if (e >= td->dstar) {
+        p.out[task] = 0.0;
+        return;
+    }
+
+    // ---- cleaned list, without moving anything: which entries are switches, and what lies behind each ---------------
+    // (the cleaning rule of kernels.hip: an entry at or beyond the trajectory's end ends the list; an empty segment and
+    // a segment in the state of its predecessor are no switches)
+    unsigned keep = 1u;   // bit i: entry i is a real switch (bit 0: the initial segment)
+    int sprev[KMAX];      // state in front of entry i
+    {
+        int prev = b[0];
+        bool dead = false;
+#pragma unroll
+        for (int i = 1; i < KMAX; ++i) {
+            sprev[i] = prev;
+            if (i < K1) {
+                const int end = (i + 1 < K1 && i + 1 < KMAX) ? a[i + 1] : INT_MAX;
+                dead = dead || a[i] >= T;
+                if (!dead && end > a[i] && b[i] != prev) {
+                    keep |= 1u << i;
+                    prev = b[i];
+                }
+            }
+        }
+    }
+    int n2[KMAX], sm[KMAX], n4[KMAX]; // behind switch i: start and state of the next switch, start of the one after
+    int first = T;                    // first switch, or T
+    {
+        int nxt_t = INT_MAX, nxt_s = 0, nxt2_t = INT_MAX;
+#pragma unroll
+        for (int i = KMAX - 1; i >= 1; --i) {
+            n2[i] = nxt_t;
+            sm[i] = nxt_s;
+            n4[i] = nxt2_t;
+            if (keep & (1u << i)) {
+                nxt2_t = nxt_t;
+                nxt_t = a[i];
+                nxt_s = b[i];
+            }
+        }
+        if (nxt_t < T) first = nxt_t;
+    }
+
+    // ---- everything the walk may need, for all switches at once ------------------------------------------------------
+    const int64_t rec_e = td->prefix_rec0 + (int64_t)e * S * T; // records of chain e: + state * T + frame
+    const int64_t tr_e = td->trans0 + (int64_t)e * S * S * T;   // entries of chain e: + (s * S + sn) * T + frame
+    auto L = [&](int st, int t) { return p.Lc[rec_e + (int64_t)st * T + t]; };
+    double v1[KMAX], v2[KMAX];
+    int m1[KMAX], m2[KMAX];
+    double extra = L(b[0], first - 1);
+#pragma unroll
+    for (int i = 1; i < KMAX; ++i) {
+        v1[i] = v2[i] = 0.0;
+        m1[i] = m2[i] = 0;
+        if (keep & (1u << i)) {
+            const int ti = a[i], s0 = sprev[i], s1 = b[i];
+            const int t3 = n2[i] < T ? n2[i] : T;
+            const TransEntry en = p.trans[tr_e + ((int64_t)s0 * S + s1) * T + ti];
+            const double la = L(s1, ti - 1), lb = L(s1, t3 - 1);
+            v1[i] = en.c + (lb - la);
+            m1[i] = en.m;
+            if (p.trans2 != nullptr && n2[i] < T && n2[i] - ti < p.gap_max) {
+                const int t4 = n4[i] < T ? n4[i] : T;
+                const TransEntry e2 =
+                    p.trans2[(td->trans0 * S + ((((int64_t)e * S + s0) * S + s1) * S + sm[i]) * T + ti) * p.gap_max + (n2[i] - ti)];
+                v2[i] = e2.c + (L(sm[i], t4 - 1) - L(sm[i], ti - 1));
+                m2[i] = e2.m;
+            }
+        }
+    }
+
+    // ---- the walk (kernels.hip: land) ---------------------------------------------------------------------------------
+    bool heavy = false, skip = false;
+#pragma unroll
+    for (int i = 1; i < KMAX; ++i) {
+        if (!(keep & (1u << i)) || heavy) continue;
+        if (skip) { // second switch of a pair that came out of the pair table
+            skip = false;
+            continue;
+        }
+        const int t3 = n2[i] < T ? n2[i] : T;
+        const int t4 = n4[i] < T ? n4[i] : T;
+        if (m1[i] > 0 && a[i] + m1[i] <= t3) {
+            extra += v1[i];
+        } else if (m2[i] > 0 && a[i] + m2[i] <= t4) {
+            extra += v2[i];
+            skip = true;
+        } else {
+            heavy = true;
+        }
+    }
+    if (!heavy) {
+        p.out[task] = extra;
+        if (p.frames_task) p.frames_task[task] = 0;
+        if (p.tasks_done) {
+            const unsigned long long done = __ballot(1);
+            if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)done) - 1)
+                atomicAdd(p.tasks_done, (unsigned long long)__popcll(done));
+        }
+        return;
+    }
+
+    // ---- a chain the tables do not cover: hand the task to the frame loop, in the bucket of its expected work ----------
+    // (the estimate of the host scheduler, api.cpp: schedule -- chains of switches less than m_typ frames apart)
+    int w = 0;
+    {
+        int run_from = -1, links = 0;
+        const int mt = p.m_typ;
+        const bool pairs = p.trans2 != nullptr;
+#pragma unroll
+        for (int i = 1; i < KMAX; ++i) {
+            if (!(keep & (1u << i))) continue;
+            const int t1 = a[i];
+            const int gap = (n2[i] < T ? n2[i] : T) - t1;
+            if (run_from < 0) {
+                if (gap < mt) {
+                    run_from = t1;
+                    links = 1;
+                }
+            } else {
+                ++links;
+                if (gap >= mt) {
+                    if (!(pairs && links == 2)) w += t1 + mt - run_from;
+                    run_from = -1;
+                }
+            }
+        }
+        if (run_from >= 0 && !(links == 1 || (pairs && links == 2))) w += T - run_from;
+    }
+    int bucket = w / kWorkBucketFrames;
+    bucket = bucket < 0 ? 0 : (bucket >= kWorkBuckets ? kWorkBuckets - 1 : bucket);
+    write_list();
+    const int pos = atomicAdd(p.work_counts + bucket, 1);
+    p.work[(int64_t)bucket * p.work_cap + pos] = (int32_t)task;
+}
+
+template <bool ST>
+int launch_st(const WalkParams &p, hipStream_t st)
+{
+    const int64_t ntasks = p.n * p.dstar_max;
+    const unsigned grid = (unsigned)((ntasks + 63) / 64);
+    // one instantiation per list length that is common in an adaptive-k run (k = K1 - 1 switches), coarser above
+#define BILD_WALK_CASE(KMAX)                                                                  \
+    if (p.K1 <= KMAX) {                                                                       \
+        hipLaunchKernelGGL((walk_kernel<KMAX, ST>), dim3(grid), dim3(64), 0, st, p);          \
+        return (int)hipGetLastError();                                                        \
+    }
+    BILD_WALK_CASE(2)
+    BILD_WALK_CASE(3)
+    BILD_WALK_CASE(4)
+    BILD_WALK_CASE(5)
+    BILD_WALK_CASE(6)
+    BILD_WALK_CASE(7)
+    BILD_WALK_CASE(8)
+    BILD_WALK_CASE(10)
+    BILD_WALK_CASE(12)
+    BILD_WALK_CASE(16)
+#undef BILD_WALK_CASE
+    return (int)hipErrorInvalidValue;
+}
+
+} // namespace
+
+int launch_walk(const WalkParams &p, void *stream)
+{
+    if (p.n <= 0) return 0;
+    if (p.n * p.dstar_max > (int64_t)INT_MAX) return (int)hipErrorInvalidValue; // task indices in the work lists are int32
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    return p.ss ? launch_st<true>(p, st) : launch_st<false>(p, st);
+}
+
+} // namespace bild

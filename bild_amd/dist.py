@@ -86,23 +86,52 @@ class LibraryComm:
         return _lib.comm_unique_id()
 
     @classmethod
-    def from_file(cls, path, world, rank, timeout=120.0):
+    def from_file(cls, path, world, rank, nonce, timeout=120.0):
+        """
+        Rendezvous through a shared file system.  `nonce` (any string without a path separator: a launch id, a job id,
+        the rank-0 pid handed out by the launcher) names THIS job: the id is exchanged through ``path + '.' + nonce``, so a
+        file left behind by an earlier run under the same `path` is never read.  Rank 0 refuses to start when the file of
+        this very nonce already exists (two jobs with one nonce), and removes it once every rank has created its
+        communicator (ranks report through ``<file>.<rank>`` markers).
+        """
         import os
         import time
         from . import _lib
+        nonce = str(nonce)
+        if not nonce or os.sep in nonce:
+            raise ValueError("nonce must be a non-empty string without a path separator")
+        file = f"{path}.{nonce}"
         if rank == 0:
-            tmp = path + '.tmp'
+            if os.path.exists(file):
+                raise FileExistsError(f"{file} exists: another job uses the same nonce (or a crashed one left it behind)")
+            tmp = file + '.tmp'
             with open(tmp, 'wb') as f:
                 f.write(_lib.comm_unique_id())
-            os.replace(tmp, path)          # appears atomically
+            os.replace(tmp, file)          # appears atomically
         t0 = time.time()
-        while not os.path.exists(path):
+        while not os.path.exists(file):
             if time.time() - t0 > timeout:
-                raise TimeoutError(f"communicator id {path} did not appear")
+                raise TimeoutError(f"communicator id {file} did not appear")
             time.sleep(0.01)
-        with open(path, 'rb') as f:
+        with open(file, 'rb') as f:
             uid = f.read()
-        return cls(world, rank, uid)
+        comm = cls(world, rank, uid)
+        # every rank has the id once its communicator exists: tell rank 0, which then removes all traces
+        if rank != 0:
+            with open(f"{file}.{rank}", 'wb'):
+                pass
+        else:
+            others = [f"{file}.{r}" for r in range(1, world)]
+            while not all(os.path.exists(o) for o in others):
+                if time.time() - t0 > timeout:
+                    break
+                time.sleep(0.01)
+            for o in others + [file]:
+                try:
+                    os.remove(o)
+                except OSError:
+                    pass
+        return comm
 
     @classmethod
     def from_torch(cls, group=None):

@@ -188,36 +188,48 @@ class MultiStateRouse(MultiStateModel):
 
         trajs : a trajectory or a list of trajectories
 
-        The cache is keyed by the IDENTITY of the trajectory objects (plus the address and shape of their data
-        and the localization errors in force), never by their contents: a lookup costs microseconds however
-        long the trajectories are.  Data changed in place are not noticed -- call `invalidate()` after doing that.
+        The cache is keyed by the IDENTITY of the trajectory objects, and an entry is trusted while the address and shape
+        of each trajectory's data, the localization errors in force and a cheap content guard (a strided subsample of
+        64 values plus the number of NaN entries) are unchanged: a lookup costs microseconds.  In-place edits that the
+        guard can see (masking frames with NaN, rescaling, refilling a preallocated array) therefore lead to a fresh
+        upload and fresh tables; an edit of single values between the guard's sample points is NOT noticed -- call
+        `invalidate()` after editing data in place.  Trajectory-likes whose ``t[:]`` builds a new array on every
+        access are keyed by a hash of their contents instead, so that they are not uploaded again on every call.
         """
         single = not isinstance(trajs, (list, tuple))
         items = (trajs,) if single else tuple(trajs)
-        key = tuple(map(id, items))
+        prints, arrs = self._fingerprints(items)
+        key = tuple(id(t) if p[0] is not None else p for t, p in zip(items, prints))
         hit = self._trajsets.get(key)
         if hit is not None:
-            ts, kept, prints = hit
-            if all(a is b for a, b in zip(kept, items)) and prints == self._fingerprints(items):
+            ts, kept, old_prints = hit
+            if all(a is b or p[0] is None for a, b, p in zip(kept, items, prints)) and old_prints == prints:
                 self._trajsets.move_to_end(key)
                 return ts
-        arrs = [as_array(t) for t in items]
-        noises = [np.asarray(self._get_noise(t), dtype=np.float64) for t in items]
+        noises = [np.frombuffer(p[2], dtype=np.float64) for p in prints]
         ts = _lib.TrajSetHandle(self.handle(), arrs, np.stack(noises))
-        self._trajsets[key] = (ts, items, self._fingerprints(items))   # `items` keeps the objects (and their ids) alive
+        self._trajsets[key] = (ts, items, prints)   # `items` keeps the objects (and their ids) alive
         while len(self._trajsets) > 8:
             self._trajsets.popitem(last=False)
         return ts
 
     def _fingerprints(self, items):
-        out = []
+        """ per trajectory: (data address or None, shape, noise bytes, content guard); and the data arrays themselves """
+        out, arrs = [], []
         for t in items:
-            a = t[:]
-            if isinstance(a, np.ndarray):
-                out.append((a.__array_interface__['data'][0], a.shape, np.asarray(self._get_noise(t)).tobytes()))
-            else:
-                out.append((None, len(t), np.asarray(self._get_noise(t)).tobytes()))
-        return out
+            view = t[:]
+            a = as_array(t)
+            arrs.append(a)
+            noise = np.ascontiguousarray(self._get_noise(t), dtype=np.float64).tobytes()
+            stable = isinstance(view, np.ndarray) and isinstance(t[:], np.ndarray) and \
+                t[:].__array_interface__['data'][0] == view.__array_interface__['data'][0]
+            if stable:
+                flat = a.reshape(-1)
+                guard = (flat[::max(1, flat.size // 64)].tobytes(), int(np.count_nonzero(flat != flat)))
+                out.append((view.__array_interface__['data'][0], a.shape, noise, guard))
+            else:   # no stable buffer to identify the data by: the contents are the key
+                out.append((None, a.shape, noise, hash(a.tobytes())))
+        return out, arrs
 
     # ------------------------------------------------------------------ likelihood
     def logL(self, profile, traj):

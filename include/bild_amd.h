@@ -61,6 +61,14 @@ typedef enum bild_status {
  * (Environment BILD_NO_JUMP=1: the same for every call.) */
 #define BILD_NO_JUMP 0x40u
 
+/* Split launches.  With all tables of a trajectory set in place a batch is launched as two kernels: a table walk with
+ * one LANE per task (csrc/walk.hip), which finishes every task that needs no Kalman frame -- 96 % of the headline batch --
+ * and appends the others to work lists ordered by expected work, and the frame loop (csrc/kernels.hip) over the listed
+ * tasks only.  The walk adds the same numbers in the same order as the frame-loop kernel would: results are bit-identical
+ * to the single launch, which this flag (or BILD_NO_SPLIT=1 in the environment) restores for A/B measurements and tests.
+ * Lists of up to 16 segments per candidate are split; longer ones always take the single launch. */
+#define BILD_NO_SPLIT 0x80u
+
 /* bild_model_create flags */
 #define BILD_MODEL_NO_REDUCE 1u /* keep all N modes: skip the invariant-subspace reduction */
 
@@ -181,6 +189,12 @@ int bild_logl_st(const bild_model *m, const bild_trajset *ts, int64_t n, int K1,
 int bild_logl_st_to_device(const bild_model *m, const bild_trajset *ts, int64_t n, int K1,
                            const double *ss, const int64_t *thetas, const int32_t *traj_id,
                            unsigned flags, void *hip_stream, double *d_out);
+
+/* bild_logl_st_to_device waits for nothing, so it cannot refuse a row that is not a point on the simplex (negative or
+ * non-finite interval lengths): such a row gets NaN as its result and the model remembers it.  This call waits for the
+ * model's pending to_device calls, returns BILD_ERR_INVALID if any row was refused since the last query (*bad_row: one
+ * of them, else -1; may be NULL) and forgets the verdict.  bild_logl_st itself reports such rows directly. */
+int bild_logl_st_status(const bild_model *m, int64_t *bad_row);
 
 /* The conversion alone (host only, no GPU): FixedkSampler.st2profile's switch frames (bild/amis.py:685-693) as
  * run-length segments.  Sample r belongs to a trajectory of T[r * T_stride] frames (T_stride 0: one length for all).
@@ -308,6 +322,8 @@ int bild_flop_count(const bild_model *m, const bild_trajset *ts, int64_t n,
  * figure.  Timing is off unless enabled. */
 int bild_kernel_timing(int enable);
 int bild_kernel_timing_read(double *total_ms, int64_t *launches, char *name, int name_len);
+/* the same for the table-walk kernel that precedes the frame loop in a split launch (see "split launches" above) */
+int bild_kernel_timing_read_walk(double *total_ms, int64_t *launches);
 
 /* ------------------------------------------------ host-side AMIS bookkeeping -------
  * SURVEY section 8, row f-1.  Plain host code (no GPU): everything reference

@@ -258,7 +258,7 @@ model = bild_amd.MultiStateRouse(20, 1, 5, d=3, localization_error=0.1)
 traj = model.trajectory_from_loopingprofile(H.random_profile(rng, 300, 2, 60), rng=rng)
 ss, thetas = H.candidate_profiles(rng, 321, 3, 2)
 host = model.logL_st_batch(ss, thetas, traj)
-comm = bdist.LibraryComm.from_file(sys.argv[2], 1, 0)            # rank 0 of 1: writes the id file and reads it back
+comm = bdist.LibraryComm.from_file(sys.argv[2], 1, 0, nonce=str(os.getpid()))            # rank 0 of 1: writes the id file and reads it back
 sm = bdist.ShardedModel(model, comm=comm, collective_at_world1=True)
 a = sm.logL_st_batch(ss, thetas, traj)
 b = sm.logL_st_batch(ss[:50], thetas[:50], traj)

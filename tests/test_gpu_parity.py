@@ -888,6 +888,8 @@ def test_prefix_table_and_launch_order_do_not_change_results(built_lib, case):
     fast = _lib.logl_segments(h, ts, seg_start, seg_state, tid)                  # + convergence jumps (the default)
     assert _lib.prefix_info(ts)[0] > 0                # a table was built
     assert np.array_equal(exact, base)
+    # the default launch is split (table walk + frame loop over the work lists, csrc/walk.hip): same numbers, same order
+    assert np.array_equal(_lib.logl_segments(h, ts, seg_start, seg_state, tid, split=False), fast)
     jump_dev = np.max(np.abs(fast - base))
     print(f"{case}: max |jumping - frame by frame| = {jump_dev:.2e} on |logL| up to {np.max(np.abs(base)):.1e}")
     assert jump_dev < 1e-9
@@ -899,14 +901,15 @@ def test_prefix_table_and_launch_order_do_not_change_results(built_lib, case):
          dict(a=seg_start, b=seg_state, t=tid, o=order).items()}
     out = torch.empty(n, dtype=torch.float64, device=dev)
     for d_order in (0, d['o'].data_ptr()):
-        for prefix, jump, want in ((True, False, base), (False, True, base), (True, True, fast)):
+        for prefix, jump, split, want in ((True, False, True, base), (False, True, True, base), (True, True, True, fast),
+                                          (True, True, False, fast)):
             out.fill_(0.0)
             _lib.logl_segments_device(h, ts, n, k + 1, d['a'].data_ptr(), d['b'].data_ptr(), d['t'].data_ptr(), out.data_ptr(),
                                       stream=torch.cuda.current_stream().cuda_stream, d_order=d_order, prefix=prefix, jump=jump,
-                                      validate=True)
+                                      split=split, validate=True)
             torch.cuda.synchronize()
             # a result depends on its own candidate only: never on the launch order or on the rest of the batch
-            assert np.array_equal(out.cpu().numpy(), want), (d_order != 0, prefix, jump)
+            assert np.array_equal(out.cpu().numpy(), want), (d_order != 0, prefix, jump, split)
     half = rng.permutation(n)[:n // 3]
     assert np.array_equal(_lib.logl_segments(h, ts, seg_start[half], seg_state[half], tid[half]), fast[half])
     # a launch order that is not a permutation is refused when validation is asked for

@@ -2,10 +2,10 @@
 How many frames does a candidate run itself (the rest comes out of the prefix table)?  Distribution over the bench's
 batch, and what that means for a wavefront (4 candidates in lockstep: the wave runs as long as its busiest row).
 
-    python tools/frames_hist.py [n] [T] [k]
+    python tests/tools/frames_hist.py [n] [T] [k]
 """
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import ctypes
 import numpy as np, torch, helpers as H, bild_amd

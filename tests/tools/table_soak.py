@@ -5,10 +5,10 @@ trajectories, batches of candidates with 1..15 switches placed to provoke chains
 at the ends, equal neighbours, empty segments), evaluated with the tables and frame by frame (BILD_NO_PREFIX, which the
 GPU tests pin to the oracle).  Prints the largest deviation per configuration; exits 1 above 1e-9.
 
-    python tools/table_soak.py [n_configs] [candidates per config]
+    python tests/tools/table_soak.py [n_configs] [candidates per config]
 """
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, helpers as H, bild_amd
 from bild_amd import _lib
@@ -47,11 +47,12 @@ for c in range(n_cfg):
     base = _lib.logl_segments(h, ts, seg_start, seg_state, tid, prefix=False)
     fast = _lib.logl_segments(h, ts, seg_start, seg_state, tid)
     again = _lib.logl_segments(h, ts, seg_start[::-1].copy(), seg_state[::-1].copy(), tid[::-1].copy())[::-1]
+    single = _lib.logl_segments(h, ts, seg_start, seg_state, tid, split=False)     # one launch instead of walk + frame loop
     dev = float(np.max(np.abs(fast - base)))
-    same = bool(np.array_equal(fast, again))
+    same = bool(np.array_equal(fast, again)) and bool(np.array_equal(fast, single))
     worst = max(worst, dev)
     print(f"config {c:3d}: S={S} N={N} d={d} trajectories {Ts} K1={K1:2d}: max |tables - frame by frame| = {dev:.2e} on |logL| <= "
-          f"{np.max(np.abs(base)):.1e}; order-independent: {same}; tables {_lib.prefix_info(ts)[0] / 1e6:.1f} MB", flush=True)
+          f"{np.max(np.abs(base)):.1e}; order- and split-independent: {same}; tables {_lib.prefix_info(ts)[0] / 1e6:.1f} MB", flush=True)
     if not same or not np.all(np.isfinite(fast)):
         print("FAILED"); sys.exit(1)
 print(f"worst deviation {worst:.2e}")
