@@ -23,6 +23,7 @@ VALIDATE_DEVICE = 0x10
 NO_PREFIX = 0x20
 NO_JUMP = 0x40
 NO_SPLIT = 0x80
+NO_STATES = 0x100
 
 Q_N, Q_D, Q_S, Q_MODAL_OK, Q_NP, Q_NEFF, Q_HAS_G = range(7)
 X_LAMBDA, X_SIGMA, X_Q, X_WQ, X_R, X_C0Q, X_V = range(7)
@@ -235,14 +236,14 @@ class TrajSetHandle:
             self._h = None
 
 
-def logl_segments(model, ts, seg_start, seg_state, traj_id=None, path='auto', prefix=True, jump=True, split=True):
+def logl_segments(model, ts, seg_start, seg_state, traj_id=None, path='auto', prefix=True, jump=True, split=True, states=True):
     seg_start, seg_state = i32(seg_start), i32(seg_state)
     n, K1 = seg_start.shape
     assert seg_state.shape == (n, K1)
     tid = None if traj_id is None else i32(traj_id)
     out = np.empty(n, dtype=np.float64)
     check(lib().bild_logl_segments(model._h, ts._h, n, K1, iptr(seg_start), iptr(seg_state), iptr(tid),
-                                   _flags(path, prefix=prefix, jump=jump, split=split), dptr(out)))
+                                   _flags(path, prefix=prefix, jump=jump, split=split, states=states), dptr(out)))
     return out
 
 
@@ -295,9 +296,9 @@ def logl_profiles(model, ts, states, traj_id=None, path='auto'):
     return out
 
 
-def _flags(path, validate=False, prefix=True, jump=True, split=True):
+def _flags(path, validate=False, prefix=True, jump=True, split=True, states=True):
     return (PATHS[path] | (VALIDATE_DEVICE if validate else 0) | (0 if prefix else NO_PREFIX) | (0 if jump else NO_JUMP) |
-            (0 if split else NO_SPLIT))
+            (0 if split else NO_SPLIT) | (0 if states else NO_STATES))
 
 
 def frames_run_read(model):
@@ -341,14 +342,14 @@ def prefix_info(ts):
 
 
 def logl_segments_device(model, ts, n, K1, d_seg_start, d_seg_state, d_traj_id, d_out, stream=0, path='auto', validate=False,
-                         d_order=0, prefix=True, jump=True, split=True):
+                         d_order=0, prefix=True, jump=True, split=True, states=True):
     """
     raw device pointers (ints); asynchronous on `stream` (validate=True: descriptors checked on the device first);
     d_order: device pointer of the launch order from `schedule_segments`, 0 = the order of the arrays
     """
     check(lib().bild_logl_segments_device_ordered(model._h, ts._h, n, K1, _vp(d_seg_start), _vp(d_seg_state),
                                           _vp(d_traj_id) if d_traj_id else None, _vp(d_order) if d_order else None,
-                                          _flags(path, validate, prefix, jump, split),
+                                          _flags(path, validate, prefix, jump, split, states),
                                           _vp(stream) if stream else None, _vp(d_out)))
 
 

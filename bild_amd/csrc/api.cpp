@@ -164,6 +164,15 @@ struct bild_model {
     mutable unsigned long long *d_frames = nullptr; // frames the tasks ran themselves, summed while kernel timing is on
     mutable hipEvent_t h_in_event = nullptr; // behind the last kernel of a call that left its results on the device (nobody waited)
     mutable bool h_in_busy = false;
+    // work lists of split launches (walk.hip): [two sets of kWorkBuckets counters, padded to 128 bytes] [kWorkBuckets lists].
+    // Launches alternate between the two sets, and the walk kernel of a launch zeroes the OTHER set -- last touched by the
+    // launch before, which has finished -- for the launch after: no launch of its own is needed to zero sixteen integers.
+    // The block serves every launch on the stream that used it first (launches on one stream run one after another);
+    // launches on other streams get a stream-ordered allocation of their own.
+    mutable DeviceBuf ws_work;
+    mutable hipStream_t work_stream = nullptr;
+    mutable bool work_stream_set = false;
+    mutable int work_set = 0;
     mutable PinnedBuf h_status; // (s, theta) rows refused on the device by calls nobody waited for: sticky until bild_logl_st_status
 };
 
@@ -199,6 +208,8 @@ struct bild_trajset {
     mutable int64_t trans2_entries = 0;
     mutable double trans2_build_ms = 0.0;
     mutable int gap_max = 0;              // gaps 1 .. gap_max - 1 are in the pair table
+    mutable double *d_strans = nullptr;   // transient state table (common.h), filled by the launch that builds the transient table
+    mutable int64_t strans_records = 0;
     mutable int trans_m_max = 0;          // longest converged transient of the single table
     mutable int trans_m_typ = 48;         // typical frames-to-convergence of the table's entries (90th percentile): the scheduler's yardstick
 };
@@ -559,6 +570,7 @@ int ensure_device(const bild_model &m)
     HIP_TRY(hipEventCreateWithFlags(&m.h_in_event, hipEventDisableTiming));
     HIP_TRY(hipMalloc((void **)&m.d_frames, kFrameCounters * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(m.d_frames, 0, kFrameCounters * sizeof(unsigned long long)));
+    HIP_TRY(hipDeviceSynchronize()); // (a memset is not ordered against the non-blocking stream just created)
     m.device = dev;
     return BILD_OK;
 }
@@ -632,7 +644,7 @@ int ensure_prefix(const bild_model &m, const bild_trajset &ts, hipStream_t st)
               hipMalloc((void **)&d_sink, (size_t)nb * ts.dstar_max * sizeof(double)) == hipSuccess &&
               hipMalloc((void **)&d_tab, bytes) == hipSuccess &&
               hipMalloc((void **)&d_L, (size_t)ts.prefix_records * sizeof(double)) == hipSuccess &&
-              hipMemset(d_L, 0, (size_t)ts.prefix_records * sizeof(double)) == hipSuccess &&
+              hipMemsetAsync(d_L, 0, (size_t)ts.prefix_records * sizeof(double), st) == hipSuccess &&
               hipMemcpy(d_desc, host.data(), host.size() * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess &&
               hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
     if (ok) {
@@ -675,16 +687,14 @@ struct SplitIn {
     const double *d_ss = nullptr;
     const int8_t *d_thetas = nullptr;
     int32_t *status = nullptr;   // [0] != 0: a row was not a point on the simplex, [1]: such a row
-    // kWorkBuckets zeroed counters, and kWorkBuckets lists of n * dstar_max task indices each; null: allocated per
-    // call on the stream (re-entrant device entry points)
-    int32_t *d_work = nullptr;
-    int32_t *d_work_lists = nullptr;
 };
 int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1, const int32_t *d_seg_start,
                  const int32_t *d_seg_state, const int32_t *d_traj_id, const int32_t *d_order, unsigned flags,
                  hipStream_t st, double *d_out, const SplitIn *sp = nullptr);
 // split launches (table walk + frame loop over the work lists) are possible for this many segments per candidate
 constexpr int kSplitMaxK1 = kSegLds;
+constexpr size_t kWorkHeader = 128; // two sets of work-list counters
+static_assert(kWorkHeader >= 2 * kWorkBuckets * sizeof(int32_t), "header holds the counters");
 
 // The transient table of a trajectory set (common.h: TransEntry), built once behind the prefix table: one ordinary
 // two-segment candidate per (trajectory, old state, new state, switch frame), evaluated by the likelihood kernel in its
@@ -723,11 +733,25 @@ int ensure_transients(const bild_model &m, const bild_trajset &ts, hipStream_t s
     hipEvent_t e0 = nullptr, e1 = nullptr;
     bool ok = hipMalloc((void **)&d_desc, host.size() * sizeof(int32_t)) == hipSuccess &&
               hipMalloc((void **)&d_sink, (size_t)nb * sizeof(double)) == hipSuccess &&
-              hipMalloc((void **)&d_tab, bytes) == hipSuccess && hipMemset(d_tab, 0, bytes) == hipSuccess &&
+              hipMalloc((void **)&d_tab, bytes) == hipSuccess && hipMemsetAsync(d_tab, 0, bytes, st) == hipSuccess &&
               hipMemcpy(d_desc, host.data(), host.size() * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess &&
               hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+    // the state table beside it (common.h: a chain of close switches starts at its second switch): an optimisation with a
+    // budget -- T x S (S - 1) x 64 records of ~1.1 KB per trajectory and chain, 141 MB for one 2-state trajectory of 1000 frames
+    double *d_states = nullptr;
+    if (ok && !getenv("BILD_NO_STATES")) {
+        const size_t sbytes = (size_t)ts.strans_records * prefix_record_doubles(m.NPm[kModal]) * sizeof(double);
+        static const size_t budget = getenv("BILD_STATES_MAX_BYTES") ? (size_t)atoll(getenv("BILD_STATES_MAX_BYTES")) : ((size_t)64 << 30);
+        if (sbytes <= budget && hipMemGetInfo(&free_b, &total_b) == hipSuccess && sbytes <= free_b / 3) {
+            if (hipMalloc((void **)&d_states, sbytes) != hipSuccess) {
+                d_states = nullptr;
+                (void)hipGetLastError();
+            }
+        }
+    }
     if (ok) {
         ts.d_trans = d_tab; // launch_batch passes it on as the table to FILL (trans_state is still -1)
+        ts.d_strans = d_states;
         (void)hipEventRecord(e0, st);
         {
             BuildingScope scope(1);
@@ -738,6 +762,7 @@ int ensure_transients(const bild_model &m, const bild_trajset &ts, hipStream_t s
         float ms = 0.f;
         if (ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) ts.trans_build_ms = ms;
         ts.d_trans = nullptr;
+        ts.d_strans = nullptr;
     }
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
@@ -771,9 +796,11 @@ int ensure_transients(const bild_model &m, const bild_trajset &ts, hipStream_t s
     }
     if (ok) {
         ts.d_trans = d_tab;
+        ts.d_strans = d_states;
         ts.trans_state = 1;
     } else {
         if (d_tab) (void)hipFree(d_tab);
+        if (d_states) (void)hipFree(d_states);
         (void)hipGetLastError();
     }
     return BILD_OK;
@@ -876,7 +903,14 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
     Geometry geom{};
     size_t lds = 0;
     if (fam == kVector) {
-        if (!geometry_for(m.NPm[mode], mode, n * ts.dstar_max, ts.means_max, &geom))
+        // A split launch (below) sends only its chains of close switches through the frame loop -- a few per cent of a
+        // batch with few switches per candidate, a third at k = 8 -- and deals them out itself, heaviest first.
+        static const bool no_split_env0 = getenv("BILD_NO_SPLIT") != nullptr;
+        const bool may_split = mode == kModal && K1 <= kSplitMaxK1 && !tl_building && !no_split_env0 && !(flags & (BILD_NO_SPLIT | BILD_NO_JUMP | BILD_NO_PREFIX)) &&
+                               ts.trans_state == 1;
+        // (the first geometry of the chain length: fewest tasks per wave, and the one whose LDS leaves room for the walk plan)
+        const int64_t tasks_for_geometry = may_split ? 1 : n * ts.dstar_max;
+        if (!geometry_for(m.NPm[mode], mode, tasks_for_geometry, ts.means_max, &geom))
             return fail(BILD_ERR_UNSUPPORTED, "no kernel for %d rows", m.NPm[mode]);
         lds = lds_bytes(m, geom, mode);
         if (lds > 160 * 1024)
@@ -903,12 +937,23 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
             const int64_t transients_after = after_env ? atoll(after_env) : kTransientsAfter;
             if (ts.prefix_state == 0 && seen >= prefix_after) ensure_prefix(m, ts, st);
             if (ts.prefix_state == 1) p.prefix = ts.d_prefix;
+            static const bool no_states = getenv("BILD_NO_STATES") != nullptr;
             if (tl_building == 1) {
                 p.trans_dump = ts.d_trans;
+                p.strans_dump = ts.d_strans;
+                p.sgap = kStateGap;
             } else if (tl_building == 2) {
                 p.trans2_dump = ts.d_trans2;
                 p.gap_max = ts.gap_max;
+                if (!no_states && !(flags & BILD_NO_STATES)) {
+                    p.strans = ts.d_strans;
+                    p.sgap = kStateGap;
+                }
             } else if (p.prefix && !p.no_jump) {
+                if (ts.trans_state == 1 && !no_states && !(flags & BILD_NO_STATES)) {
+                    p.strans = ts.d_strans;
+                    p.sgap = kStateGap;
+                }
                 if (ts.trans_state == 0 && seen >= transients_after) ensure_transients(m, ts, st);
                 if (ts.trans_state == 1) {
                     p.trans = ts.d_trans;
@@ -981,17 +1026,38 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
         }
         w.convert_all = split ? 0 : 1;
         if (split) {
-            int32_t *d_work = sp ? sp->d_work : nullptr, *d_lists = sp ? sp->d_work_lists : nullptr;
-            if (!d_work || !d_lists) {
-                const size_t bytes = ((size_t)kWorkBuckets + (size_t)kWorkBuckets * (size_t)p.ntasks) * sizeof(int32_t);
-                hipError_t he = hipMallocAsync((void **)&work_alloc, bytes, st);
-                if (he == hipSuccess) he = hipMemsetAsync(work_alloc, 0, kWorkBuckets * sizeof(int32_t), st);
+            int32_t *d_work = nullptr, *d_lists = nullptr;
+            const size_t list_bytes = (size_t)kWorkBuckets * (size_t)p.ntasks * sizeof(int32_t);
+            {
+                std::lock_guard<std::mutex> lk(m.mu);
+                if (!m.work_stream_set) {
+                    m.work_stream = st;
+                    m.work_stream_set = true;
+                }
+                if (m.work_stream == st) {
+                    if (m.ws_work.cap < kWorkHeader + list_bytes) {
+                        // (hipFree inside waits for the device: nothing still reads the old block)
+                        // (the memset on the launch's own stream: a plain hipMemset is not ordered against a non-blocking stream)
+                        if (m.ws_work.reserve(kWorkHeader + list_bytes) != BILD_OK || hipMemsetAsync(m.ws_work.ptr, 0, kWorkHeader, st) != hipSuccess) {
+                            release();
+                            return fail(BILD_ERR_NOMEM, "work lists: allocation of %zu bytes failed", kWorkHeader + list_bytes);
+                        }
+                    }
+                    d_work = (int32_t *)m.ws_work.ptr + kWorkBuckets * m.work_set;
+                    w.work_counts_next = (int32_t *)m.ws_work.ptr + kWorkBuckets * (1 - m.work_set);
+                    m.work_set = 1 - m.work_set;
+                    d_lists = (int32_t *)((char *)m.ws_work.ptr + kWorkHeader);
+                }
+            }
+            if (!d_work) {
+                hipError_t he = hipMallocAsync((void **)&work_alloc, kWorkHeader + list_bytes, st);
+                if (he == hipSuccess) he = hipMemsetAsync(work_alloc, 0, kWorkHeader, st);
                 if (he != hipSuccess) {
                     release();
                     return fail(BILD_ERR_NOMEM, "work lists: %s", hipGetErrorString(he));
                 }
                 d_work = work_alloc;
-                d_lists = work_alloc + kWorkBuckets;
+                d_lists = (int32_t *)((char *)work_alloc + kWorkHeader);
             }
             w.Lc = ts.d_prefix_L;
             w.trans = p.trans;
@@ -1253,15 +1319,12 @@ struct StageClock {
 };
 
 // Device block of a host-buffer call (ws_in), filled by ONE copy out of the pinned block of the same layout:
-//   [ header: kWorkBuckets work-list counters, zero | status word, bad row, padding ]        kStagedHeader bytes
+//   [ header: reserved, zero ]                                                               kStagedHeader bytes
 //   [ payload: segment lists (seg_start | seg_state), or (s, theta) rows (ss float64 | thetas uint8, padded to 8 bytes) ]
 //   [ traj_id (n int32), when given ] [ launch order (n int32), when the host scheduled ]
 // and behind what is copied, device only:
 //   [ (s, theta) input: the segment lists the walk kernel writes for the frame loop: seg_start | seg_state ]
-//   [ work lists: kWorkBuckets x (n * dstar_max) int32 ]
-// The zero header travels with the payload, so the counters need no memset of their own.
 constexpr size_t kStagedHeader = 128;
-static_assert(kStagedHeader >= (kWorkBuckets + 2) * sizeof(int32_t), "header holds the counters and the status");
 
 template <typename Fill>
 int run_staged(const bild_model *m, const bild_trajset *ts, int64_t n, int K1, const int32_t *traj_id, unsigned flags,
@@ -1274,11 +1337,9 @@ int run_staged(const bild_model *m, const bild_trajset *ts, int64_t n, int K1, c
                 return fail(BILD_ERR_INVALID, "traj_id[%lld]=%d out of range", (long long)r, traj_id[r]);
     std::lock_guard<std::mutex> call_lock(m->call_mu);
     const size_t nseg = (size_t)n * K1;
-    const size_t ntasks = (size_t)n * ts->dstar_max;
     const size_t payload = st_payload ? nseg * sizeof(double) + ((nseg + 7) & ~(size_t)7) : 2 * nseg * sizeof(int32_t);
     const size_t copy_cap = kStagedHeader + payload + 2 * (size_t)n * sizeof(int32_t); // room for traj_id and the launch order
     const size_t lists = st_payload ? 2 * nseg * sizeof(int32_t) : 0;
-    const size_t work = K1 <= kSplitMaxK1 ? (size_t)kWorkBuckets * ntasks * sizeof(int32_t) : 0;
     // A previous call that left its results on the device (bild_logl_st_to_device: nothing waited for) may still be
     // running: its kernels read the device block and the work lists, its copy reads the pinned block.  The event was
     // recorded behind its last kernel.
@@ -1287,7 +1348,7 @@ int run_staged(const bild_model *m, const bild_trajset *ts, int64_t n, int K1, c
     {
         std::lock_guard<std::mutex> lk(m->mu);
         if ((rc = m->h_in.reserve(copy_cap))) return rc;
-        if ((rc = m->ws_in.reserve(copy_cap + lists + work))) return rc;
+        if ((rc = m->ws_in.reserve(copy_cap + lists))) return rc;
         if ((rc = m->h_out.reserve((size_t)n * sizeof(double) + 64))) return rc; // (+ the status word of (s, theta) input)
         if (!d_out_user && (rc = m->ws_out.reserve((size_t)n * sizeof(double)))) return rc;
     }
@@ -1329,10 +1390,6 @@ int run_staged(const bild_model *m, const bild_trajset *ts, int64_t n, int K1, c
     } else {
         d_start = (int32_t *)(d_base + kStagedHeader);
         d_state = d_start + nseg;
-    }
-    if (work) {
-        sp.d_work = (int32_t *)d_base; // the zero header
-        sp.d_work_lists = (int32_t *)(d_base + copy_cap + lists);
     }
     double *d_out = d_out_user ? d_out_user : (double *)m->ws_out.ptr;
     hipStream_t st = d_out_user ? st_user : m->stream;
@@ -1437,6 +1494,7 @@ int bild_model_destroy(bild_model *m)
     m->ws_in.release();
     m->ws_out.release();
     m->ws_sched.release();
+    m->ws_work.release();
     m->h_in.release();
     m->h_out.release();
     m->h_status.release();
@@ -1587,8 +1645,10 @@ int bild_trajset_create(const bild_model *m, int n_traj, const int32_t *T, const
         for (int j = 0; j < n_traj; ++j) {
             ts->descs[j].prefix_rec0 = rec;
             ts->descs[j].trans0 = rec * m->S; // S entries (one per new state) for every prefix record
+            ts->descs[j].strans0 = rec * (m->S - 1); // S - 1 switches (one per OTHER state) for every prefix record
             rec += (int64_t)T[j] * m->S * ts->dstar_max;
         }
+        ts->strans_records = rec * (m->S - 1) * kStateGap;
         ts->prefix_records = rec;
         ts->trans_entries = rec * m->S;
     }
@@ -1611,6 +1671,7 @@ int bild_trajset_destroy(bild_trajset *ts)
     if (ts->d_prefix_L) (void)hipFree(ts->d_prefix_L);
     if (ts->d_trans) (void)hipFree(ts->d_trans);
     if (ts->d_trans2) (void)hipFree(ts->d_trans2);
+    if (ts->d_strans) (void)hipFree(ts->d_strans);
     delete ts;
     return BILD_OK;
 }
@@ -1757,7 +1818,8 @@ int bild_prefix_info(const bild_trajset *ts, int64_t *bytes, double *build_ms)
     if (bytes)
         *bytes = (built ? ts->prefix_records * prefix_record_doubles(ts->model->NPm[kModal]) * (int64_t)sizeof(double) : 0) +
                  (trans ? ts->trans_entries * (int64_t)sizeof(TransEntry) : 0) +
-                 (pairs ? ts->trans2_entries * (int64_t)sizeof(TransEntry) : 0);
+                 (pairs ? ts->trans2_entries * (int64_t)sizeof(TransEntry) : 0) +
+                 (trans && ts->d_strans ? ts->strans_records * prefix_record_doubles(ts->model->NPm[kModal]) * (int64_t)sizeof(double) : 0);
     if (build_ms)
         *build_ms = (built ? ts->prefix_build_ms : 0.0) + (trans ? ts->trans_build_ms : 0.0) + (pairs ? ts->trans2_build_ms : 0.0);
     return BILD_OK;

@@ -49,6 +49,7 @@ struct TrajDesc {
     int64_t prefix_rec0;     // first record of this trajectory in the prefix table (records, see prefix_record_doubles)
     double xscale;           // largest |coordinate| of the data: absolute floor of the mean-vector comparison
     int64_t trans0;          // first entry of this trajectory in the transient table
+    int64_t strans0;         // first record of this trajectory in the transient state table
 };
 
 // Transient table (vector kernels, modal path, beside the prefix table): entry of (trajectory, chain e, old state s, new
@@ -75,6 +76,16 @@ struct TransEntry {
 // log-likelihood L of the frames so far, the number of observed frames so far, pad.
 // Records of trajectory j: prefix_rec0 + ((e * S + s) * T + t).
 constexpr int prefix_record_doubles(int NP) { return (NP + kDMax) * NP + kDMax + 2 + 3; }
+// Transient state table (vector kernels, modal path).  The candidates that build the transient table run, for every
+// (trajectory, chain e, old state s, new state sn != s, frame t), the frames t, t + 1, ... in state sn from the switch-free
+// filter of s -- exactly what a candidate with a switch s -> sn at t runs until its NEXT switch.  They leave their state
+// after g = 1 .. kStateGap - 1 frames (same record layout as the prefix table: [C | M], sums of e^2/S, mantissa / exponent
+// of the product of S, observed frames; the running log-likelihood is not used).  A chain of close switches -- a
+// transient that has not converged when the next switch comes -- then starts at its second switch from the record
+// (t, g = distance of the two switches) and continues the record's accumulators: the same numbers the candidate itself
+// would have produced, bit for bit, without running the g frames in between.  Records of
+// (trajectory, e, s, sn, t):  strans0 + ((((e * S + s) * (S - 1) + (sn - (sn > s))) * T + t) * kStateGap + g).
+constexpr int kStateGap = 64;
 
 struct KParams {
     const double *states; // S state blocks
@@ -107,6 +118,11 @@ struct KParams {
     int32_t gap_max;          // gaps 1 .. gap_max - 1 have entries in the pair table
     int32_t walk_lds;         // the launch has kWalkDoubles of LDS per task behind the segment lists (see logl_kernel: walk plan)
     double *prefix_L_dump;    // with prefix_dump: the running log-likelihood of every record once more, densely (8 B per record)
+    // transient STATE table (see below): a chain of close switches starts at its SECOND switch, from the state the first
+    // transient has reached there
+    const double *strans;
+    double *strans_dump;      // non-null: this launch (the one that builds the transient table) also fills the state table
+    int32_t sgap;             // records per switch: states 1 .. sgap - 1 frames behind it
     // work lists (walk.hip): this launch runs only the tasks the table walk could not finish -- kWorkBuckets lists of
     // `work_cap` task indices (index into `out`) each, heaviest bucket last, with their lengths in work_counts
     const int32_t *work;
@@ -143,10 +159,12 @@ struct WalkParams {
     int32_t gap_max, m_typ;
     double *out;            // results of the tasks that need no frame
     int32_t *work;          // kWorkBuckets x work_cap
-    int32_t *work_counts;   // kWorkBuckets, zeroed by the caller
+    int32_t *work_counts;   // kWorkBuckets, zero at launch
+    int32_t *work_counts_next; // non-null: the set of counters the next launch on this workspace will use; zeroed here
     int64_t work_cap;
     unsigned long long *tasks_done; // non-null (bench accounting): tasks finished by the walk
     int32_t *frames_task;           // non-null (diagnostics): a task finished here ran no frame
+    int32_t debug;                  // timing experiments only (BILD_WALK_DEBUG; wrong results): 1 no pair loads, 2 no append, 4 no loads at all
 };
 int launch_walk(const WalkParams &p, void *stream);
 

@@ -176,8 +176,8 @@ __device__ __forceinline__ void matvec_to_lds(XPtr X, const Cols<NP, CPL> &in, d
 // DUMP: this instantiation builds the prefix table (one per chain length is compiled, see launch_geom)
 // JUMP: this instantiation carries the machinery that takes frames out of the tables (convergence checks, transient table);
 // the frame-by-frame instantiation stays lean (the jump code costs registers the frame loop then spills around)
-template <int NP, int CPL, int G, int W, int OCC, int LAY, int MODE, int FLAVOR, bool DUMP = false, bool JUMP = false>
-__global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
+template <int NP, int CPL, int G, int W, int OCC, int LAY, int MODE, int FLAVOR, bool DUMP, bool JUMP>
+__device__ __forceinline__ void logl_body(const KParams &p)
 {
     constexpr bool HASG = FLAVOR == 0;
     constexpr bool ALLVALID = FLAVOR == 2;
@@ -749,8 +749,7 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
         double xc[CPL], xn[CPL], pc, pn;
         // start a run of own frames at frame t0 from the table's state in front of it; the trajectory pointers stand at
         // frame t_ptr (0 at the start of a task, t + 1 inside the frame loop)
-        auto start_run = [&](int t0, bool cumulative, int t_ptr) {
-            const double *__restrict__ rec = record(t0 - 1);
+        auto start_from = [&](const double *__restrict__ rec, int t0, bool cumulative, int t_ptr) {
             load_cols(rec);
             if (cumulative) { // accumulators continue the table's (BILD_NO_JUMP: bit-identical to the run from frame 0)
 #pragma unroll
@@ -772,6 +771,29 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
             nrun -= t0;
             t_check = t0 + 8; // (a switch at t0 sets its own; lists too long to be cleaned may hold boundaries that switch nothing)
             open_run = true;
+        };
+        auto start_run = [&](int t0, bool cumulative, int t_ptr) { start_from(record(t0 - 1), t0, cumulative, t_ptr); };
+        // A chain of close switches begins at the synchronised point in front of frame t (the start of segment seg + 1).  With
+        // the transient state table (common.h) it begins at its SECOND switch instead: the state the first transient has
+        // reached there, accumulators included, is a record of the table -- written by the candidate that built the transient
+        // table's entry for this switch, which ran the very same frames from the very same record.
+        auto begin_chain = [&](int t_ptr) {
+            if constexpr (JUMP) {
+                if (p.strans != nullptr && seg_in_lds && seg + 2 < nseg) {
+                    const int sn = seg_state_of(seg + 1), t2 = seg_start_of(seg + 2), g1 = t2 - t;
+                    if (sn != s && g1 >= 1 && g1 < p.sgap) {
+                        const int64_t entry = (((int64_t)e * S + s) * (S - 1) + (sn - (sn > s ? 1 : 0))) * T + t;
+                        const double *__restrict__ rec = p.strans + ((td->strans0 + entry) * p.sgap + g1) * REC;
+                        ++seg; // the segment of sn: the frame at t2 moves on to the next one
+                        s = sn;
+                        next_start = t2;
+                        t = t2;
+                        start_from(rec, t2, true, t_ptr);
+                        return;
+                    }
+                }
+            }
+            start_run(t, false, t_ptr);
         };
         // The walk plan.  Which table entries a task may need is known from its (cleaned) segment list alone: for the switch
         // into segment i, the transient entry of (state i-1 -> state i, frame start_i) and, where segment i is shorter than the
@@ -880,7 +902,7 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
 #if defined(BILD_TASK_CLOCK) && BILD_TASK_CLOCK == 3
             clock_c = wall_clock64(); // tables walked
 #endif
-            if (t < T) start_run(t, false, 0);
+            if (t < T) begin_chain(0);
         } else if (restore) {
             t = next_start < 1 ? 1 : (next_start < T ? next_start : T);
             start_run(t, true, 0);
@@ -912,6 +934,30 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
                 if (p.prefix_L_dump) p.prefix_L_dump[td->prefix_rec0 + ((int64_t)e * S + s) * T + tt] = Lsofar;
             }
         };
+        // this launch builds the transient table and, beside it, the transient state table (common.h): the state after
+        // every frame of the transient goes to its record (tasks have two segments: the switch is at sst[1])
+        const bool dump_states = JUMP && building_transients && p.strans_dump != nullptr && K1 == 2 && nseg == 2;
+        const int t_switch = dump_states ? seg_start_of(1) : 0;
+        const int64_t state_rec0 = dump_states ? (td->strans0 + (((int64_t)e * S + seg_state_of(0)) * (S - 1) +
+                                                                 (seg_state_of(1) - (seg_state_of(1) > seg_state_of(0) ? 1 : 0))) * T + t_switch) * p.sgap
+                                               : 0;
+        auto dump_state = [&](int g) {
+            double *__restrict__ rec = p.strans_dump + (state_rec0 + g) * REC;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+                if (hasImg[q]) {
+#pragma unroll
+                    for (int i = 0; i < NP; i += 2)
+                        *reinterpret_cast<double2 *>(rec + cidx[q] * NP + i) = make_double2(col.v[q][i], col.v[q][i + 1]);
+                }
+                if (isM[q]) rec[NC * NP + (cidx[q] - NP)] = accq[q];
+            }
+            if (gl == 0) {
+                rec[kRecP] = P;
+                rec[kRecE] = (double)E;
+                rec[kRecNv] = (double)nv;
+            }
+        };
         if constexpr (DUMP) dump(0);
         while (t < T) {
             // invariant: xn holds frame t, the pointers stand at frame t + 1
@@ -928,6 +974,9 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
                 // long chains that end a launch -- then waited for L2 in every frame: 0.45 us per frame instead of 0.24)
 #pragma unroll
                 for (int q = 0; q < CPL; ++q) asm volatile("" : "+v"(xn[q]));
+            }
+            if constexpr (JUMP) {
+                if (dump_states && t < T && t - t_switch < p.sgap) dump_state(t - t_switch);
             }
             if (JUMP && jumping && t == t_check && t < T) {
 #if defined(BILD_TASK_CLOCK) && BILD_TASK_CLOCK == 2
@@ -975,7 +1024,7 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
                     extra += record(t2 - 1)[kRecL] - rec[kRecL];
                     t = t2;
                     land();
-                    if (t < T) start_run(t, false, t_ptr);
+                    if (t < T) begin_chain(t_ptr);
                 }
 #if defined(BILD_TASK_CLOCK) && BILD_TASK_CLOCK == 2
                 clock_events += wall_clock64() - ev0;
@@ -1026,6 +1075,12 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
 #endif
         wave_lds_fence();
     }
+}
+
+template <int NP, int CPL, int G, int W, int OCC, int LAY, int MODE, int FLAVOR, bool DUMP = false, bool JUMP = false>
+__global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
+{
+    logl_body<NP, CPL, G, W, OCC, LAY, MODE, FLAVOR, DUMP, JUMP>(p);
 }
 
 __global__ void reduce_partials_kernel(const double *__restrict__ partial, double *__restrict__ out, int64_t n,

@@ -23,20 +23,24 @@
 // kernel starts them from scratch.
 #include <hip/hip_runtime.h>
 #include <limits.h>
+#include <stdlib.h>
 
 #include "common.h"
 
 namespace bild {
 namespace {
 
+// K1 = segments per candidate, a compile-time constant: every loop over the list unrolls without a trip-count test in
+// between, so that the loads of the list go out back to back (with the test, each pair of loads was waited for before
+// the next was issued: K1 memory round trips instead of one).
+// returns the work-list bucket of a task that goes on to the frame loop, -1 for a task that is done
 template <int KMAX, bool ST>
-__global__ void __launch_bounds__(64) walk_kernel(const WalkParams p)
+__device__ __forceinline__ int walk_task(const WalkParams &p, const int64_t task)
 {
-    const int64_t task = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (task >= p.n * p.dstar_max) return;
+    constexpr int K1 = KMAX;
     const int64_t r = task / p.dstar_max;
     const int e = (int)(task - r * p.dstar_max);
-    const int K1 = p.K1, S = p.S;
+    const int S = p.S;
     const int tj = p.traj_id ? p.traj_id[r] : 0;
     const TrajDesc *__restrict__ td = p.trajs + tj;
     const int T = td->T;
@@ -54,6 +58,9 @@ __global__ void __launch_bounds__(64) walk_kernel(const WalkParams p)
         for (int i = 0; i < KMAX; ++i) {
             a[i] = INT_MAX;
             b[i] = 0;
+        }
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i) {
             if (i < K1) {
                 const int st = th[i];
                 ok = ok && st < S;
@@ -76,7 +83,7 @@ __global__ void __launch_bounds__(64) walk_kernel(const WalkParams p)
             // not a point on the simplex (or a state out of range): nothing of this row drives an address
             if (atomicCAS(p.status, 0, 1) == 0) p.status[1] = (int)(r < INT_MAX ? r : INT_MAX);
             if (!p.convert_all) p.out[task] = __longlong_as_double(0x7ff8000000000000ll);
-            return;
+            return -1;
         }
     } else {
         const int32_t *__restrict__ sst = p.seg_start + r * K1;
@@ -105,11 +112,11 @@ __global__ void __launch_bounds__(64) walk_kernel(const WalkParams p)
     };
     if (p.convert_all) {
         write_list();
-        return;
+        return -1;
     }
     if (e >= td->dstar) {
         p.out[task] = 0.0;
-        return;
+        return -1;
     }
 
     // ---- cleaned list, without moving anything: which entries are switches, and what lies behind each ---------------
@@ -152,29 +159,56 @@ __global__ void __launch_bounds__(64) walk_kernel(const WalkParams p)
     }
 
     // ---- everything the walk may need, for all switches at once ------------------------------------------------------
+    // Loads of a group of switches are issued together, unconditionally and without a branch in between (a switch that
+    // is none reads entry 0 of the tables): one memory round trip per group instead of one per switch.
     const int64_t rec_e = td->prefix_rec0 + (int64_t)e * S * T; // records of chain e: + state * T + frame
     const int64_t tr_e = td->trans0 + (int64_t)e * S * S * T;   // entries of chain e: + (s * S + sn) * T + frame
-    auto L = [&](int st, int t) { return p.Lc[rec_e + (int64_t)st * T + t]; };
+    const double *__restrict__ Lc = p.Lc + rec_e;
+    const TransEntry *__restrict__ tr1 = p.trans + tr_e;
+    const bool pairs = p.trans2 != nullptr && !(p.debug & 1);
+    const TransEntry *__restrict__ tr2 = pairs ? p.trans2 : p.trans; // (no pair table: the loads still need an address)
+    const int64_t tr2_e = pairs ? (td->trans0 * S + (int64_t)e * S * S * S * T) * p.gap_max : 0;
     double v1[KMAX], v2[KMAX];
     int m1[KMAX], m2[KMAX];
-    double extra = L(b[0], first - 1);
+    double extra = Lc[(int64_t)b[0] * T + (first - 1)];
+    constexpr int kGroup = 5;
+    if (p.debug & 4) {
+        p.out[task] = extra;
+        return -1;
+    }
 #pragma unroll
-    for (int i = 1; i < KMAX; ++i) {
-        v1[i] = v2[i] = 0.0;
-        m1[i] = m2[i] = 0;
-        if (keep & (1u << i)) {
-            const int ti = a[i], s0 = sprev[i], s1 = b[i];
-            const int t3 = n2[i] < T ? n2[i] : T;
-            const TransEntry en = p.trans[tr_e + ((int64_t)s0 * S + s1) * T + ti];
-            const double la = L(s1, ti - 1), lb = L(s1, t3 - 1);
-            v1[i] = en.c + (lb - la);
-            m1[i] = en.m;
-            if (p.trans2 != nullptr && n2[i] < T && n2[i] - ti < p.gap_max) {
-                const int t4 = n4[i] < T ? n4[i] : T;
-                const TransEntry e2 =
-                    p.trans2[(td->trans0 * S + ((((int64_t)e * S + s0) * S + s1) * S + sm[i]) * T + ti) * p.gap_max + (n2[i] - ti)];
-                v2[i] = e2.c + (L(sm[i], t4 - 1) - L(sm[i], ti - 1));
-                m2[i] = e2.m;
+    for (int g0 = 1; g0 < KMAX; g0 += kGroup) {
+        TransEntry en[kGroup], e2[kGroup];
+        double la[kGroup], lb[kGroup], l2[kGroup], l4[kGroup];
+        bool pair_ok[kGroup];
+#pragma unroll
+        for (int j = 0; j < kGroup; ++j) {
+            const int i = g0 + j;
+            if (i < KMAX) {
+                const bool kp = (keep >> i) & 1u;
+                const int ti = kp ? a[i] : 1, s0 = kp ? sprev[i] : 0, s1 = kp ? b[i] : 0;
+                const int t3 = (kp && n2[i] < T) ? n2[i] : T;
+                pair_ok[j] = kp && pairs && n2[i] < T && n2[i] - ti < p.gap_max;
+                const int smj = pair_ok[j] ? sm[i] : 0;
+                const int t4 = (pair_ok[j] && n4[i] < T) ? n4[i] : T;
+                const int64_t i2 = pair_ok[j] ? tr2_e + ((((int64_t)s0 * S + s1) * S + smj) * T + ti) * p.gap_max + (n2[i] - ti) : 0;
+                en[j] = tr1[((int64_t)s0 * S + s1) * T + ti];
+                la[j] = Lc[(int64_t)s1 * T + (ti - 1)];
+                lb[j] = Lc[(int64_t)s1 * T + (t3 - 1)];
+                e2[j] = tr2[i2];
+                l2[j] = Lc[(int64_t)smj * T + (ti - 1)];
+                l4[j] = Lc[(int64_t)smj * T + (t4 - 1)];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kGroup; ++j) {
+            const int i = g0 + j;
+            if (i < KMAX) {
+                const bool kp = (keep >> i) & 1u;
+                v1[i] = en[j].c + (lb[j] - la[j]);
+                m1[i] = kp ? en[j].m : 0;
+                v2[i] = e2[j].c + (l4[j] - l2[j]);
+                m2[i] = pair_ok[j] ? e2[j].m : 0;
             }
         }
     }
@@ -207,7 +241,7 @@ __global__ void __launch_bounds__(64) walk_kernel(const WalkParams p)
             if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)done) - 1)
                 atomicAdd(p.tasks_done, (unsigned long long)__popcll(done));
         }
-        return;
+        return -1;
     }
 
     // ---- a chain the tables do not cover: hand the task to the frame loop, in the bucket of its expected work ----------
@@ -240,21 +274,47 @@ __global__ void __launch_bounds__(64) walk_kernel(const WalkParams p)
     int bucket = w / kWorkBucketFrames;
     bucket = bucket < 0 ? 0 : (bucket >= kWorkBuckets ? kWorkBuckets - 1 : bucket);
     write_list();
-    const int pos = atomicAdd(p.work_counts + bucket, 1);
-    p.work[(int64_t)bucket * p.work_cap + pos] = (int32_t)task;
+    return bucket;
+}
+
+constexpr int kWalkThreads = 256;
+
+template <int KMAX, bool ST>
+__global__ void __launch_bounds__(kWalkThreads) walk_kernel(const WalkParams p)
+{
+    // Appending to the work lists: positions are handed out per workgroup in LDS, then ONE global atomic per bucket and
+    // workgroup reserves the group's stretch of the list.  (Per-task atomics on sixteen words serialise in L2; so do
+    // per-wave ones once a launch has thousands of waves: 25 us of a 200 000-candidate launch.)
+    __shared__ int cnt[kWorkBuckets], base[kWorkBuckets];
+    const int tid = threadIdx.x;
+    const int64_t task = (int64_t)blockIdx.x * kWalkThreads + tid;
+    if (tid < kWorkBuckets) cnt[tid] = 0;
+    // the counters of the NEXT launch on this workspace (the other of two sets): nobody reads or writes them now
+    if (p.work_counts_next != nullptr && task < kWorkBuckets) p.work_counts_next[task] = 0;
+    __syncthreads();
+    int bucket = -1;
+    if (task < p.n * p.dstar_max) bucket = walk_task<KMAX, ST>(p, task);
+    if (p.debug & 2) bucket = -1;
+    int pos = 0;
+    if (bucket >= 0) pos = atomicAdd(&cnt[bucket], 1);
+    __syncthreads();
+    if (tid < kWorkBuckets && cnt[tid] > 0) base[tid] = atomicAdd(p.work_counts + tid, cnt[tid]);
+    __syncthreads();
+    if (bucket >= 0) p.work[(int64_t)bucket * p.work_cap + base[bucket] + pos] = (int32_t)task;
 }
 
 template <bool ST>
 int launch_st(const WalkParams &p, hipStream_t st)
 {
     const int64_t ntasks = p.n * p.dstar_max;
-    const unsigned grid = (unsigned)((ntasks + 63) / 64);
-    // one instantiation per list length that is common in an adaptive-k run (k = K1 - 1 switches), coarser above
+    const unsigned grid = (unsigned)((ntasks + kWalkThreads - 1) / kWalkThreads);
+    // one instantiation per list length (k = K1 - 1 switches per candidate)
 #define BILD_WALK_CASE(KMAX)                                                                  \
-    if (p.K1 <= KMAX) {                                                                       \
-        hipLaunchKernelGGL((walk_kernel<KMAX, ST>), dim3(grid), dim3(64), 0, st, p);          \
+    if (p.K1 == KMAX) {                                                                       \
+        hipLaunchKernelGGL((walk_kernel<KMAX, ST>), dim3(grid), dim3(kWalkThreads), 0, st, p);          \
         return (int)hipGetLastError();                                                        \
     }
+    BILD_WALK_CASE(1)
     BILD_WALK_CASE(2)
     BILD_WALK_CASE(3)
     BILD_WALK_CASE(4)
@@ -262,8 +322,13 @@ int launch_st(const WalkParams &p, hipStream_t st)
     BILD_WALK_CASE(6)
     BILD_WALK_CASE(7)
     BILD_WALK_CASE(8)
+    BILD_WALK_CASE(9)
     BILD_WALK_CASE(10)
+    BILD_WALK_CASE(11)
     BILD_WALK_CASE(12)
+    BILD_WALK_CASE(13)
+    BILD_WALK_CASE(14)
+    BILD_WALK_CASE(15)
     BILD_WALK_CASE(16)
 #undef BILD_WALK_CASE
     return (int)hipErrorInvalidValue;
@@ -274,6 +339,7 @@ int launch_st(const WalkParams &p, hipStream_t st)
 int launch_walk(const WalkParams &p, void *stream)
 {
     if (p.n <= 0) return 0;
+    if (const char *dbg = getenv("BILD_WALK_DEBUG")) const_cast<WalkParams &>(p).debug = atoi(dbg);
     if (p.n * p.dstar_max > (int64_t)INT_MAX) return (int)hipErrorInvalidValue; // task indices in the work lists are int32
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     return p.ss ? launch_st<true>(p, st) : launch_st<false>(p, st);

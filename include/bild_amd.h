@@ -69,6 +69,11 @@ typedef enum bild_status {
  * Lists of up to 16 segments per candidate are split; longer ones always take the single launch. */
 #define BILD_NO_SPLIT 0x80u
 
+/* Do not start chains of close switches from the transient state table (see "prefix table" below: the state a transient
+ * has reached when the next switch comes is a record of that table): every chain runs from its first switch.  Results are
+ * bit-identical either way.  (Environment BILD_NO_STATES=1: never build the table.) */
+#define BILD_NO_STATES 0x100u
+
 /* bild_model_create flags */
 #define BILD_MODEL_NO_REDUCE 1u /* keep all N modes: skip the invariant-subspace reduction */
 

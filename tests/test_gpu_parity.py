@@ -890,6 +890,9 @@ def test_prefix_table_and_launch_order_do_not_change_results(built_lib, case):
     assert np.array_equal(exact, base)
     # the default launch is split (table walk + frame loop over the work lists, csrc/walk.hip): same numbers, same order
     assert np.array_equal(_lib.logl_segments(h, ts, seg_start, seg_state, tid, split=False), fast)
+    # ... and chains of close switches start at their second switch, from the transient state table: the same numbers again
+    assert np.array_equal(_lib.logl_segments(h, ts, seg_start, seg_state, tid, states=False), fast)
+    assert np.array_equal(_lib.logl_segments(h, ts, seg_start, seg_state, tid, states=False, split=False), fast)
     jump_dev = np.max(np.abs(fast - base))
     print(f"{case}: max |jumping - frame by frame| = {jump_dev:.2e} on |logL| up to {np.max(np.abs(base)):.1e}")
     assert jump_dev < 1e-9

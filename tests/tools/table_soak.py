@@ -48,11 +48,12 @@ for c in range(n_cfg):
     fast = _lib.logl_segments(h, ts, seg_start, seg_state, tid)
     again = _lib.logl_segments(h, ts, seg_start[::-1].copy(), seg_state[::-1].copy(), tid[::-1].copy())[::-1]
     single = _lib.logl_segments(h, ts, seg_start, seg_state, tid, split=False)     # one launch instead of walk + frame loop
+    nostate = _lib.logl_segments(h, ts, seg_start, seg_state, tid, states=False)   # chains run from their first switch
     dev = float(np.max(np.abs(fast - base)))
-    same = bool(np.array_equal(fast, again)) and bool(np.array_equal(fast, single))
+    same = bool(np.array_equal(fast, again)) and bool(np.array_equal(fast, single)) and bool(np.array_equal(fast, nostate))
     worst = max(worst, dev)
     print(f"config {c:3d}: S={S} N={N} d={d} trajectories {Ts} K1={K1:2d}: max |tables - frame by frame| = {dev:.2e} on |logL| <= "
-          f"{np.max(np.abs(base)):.1e}; order- and split-independent: {same}; tables {_lib.prefix_info(ts)[0] / 1e6:.1f} MB", flush=True)
+          f"{np.max(np.abs(base)):.1e}; order-, split- and state-table-independent: {same}; tables {_lib.prefix_info(ts)[0] / 1e6:.1f} MB", flush=True)
     if not same or not np.all(np.isfinite(fast)):
         print("FAILED"); sys.exit(1)
 print(f"worst deviation {worst:.2e}")
