@@ -94,6 +94,7 @@ _SIGNATURES = {
     'bild_amis_sample_traces': (ctypes.c_int, [_vp, ctypes.c_int64, _dp, _vp]),
     'bild_amis_step': (ctypes.c_int, [_vp, ctypes.c_int64, _dp, _vp, _dp, _dp]),
     'bild_amis_use_device': (ctypes.c_int, [_vp, ctypes.c_int]),
+    'bild_amis_step_fused': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, _dp, _vp, ctypes.c_uint, _dp]),
     'bild_interval_marginals': (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int64, _ip, _ip, _dp, _dp]),
     'bild_choice_counts': (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, _dp, _dp, _dp, ctypes.c_double, _vp, _vp, _vp, _vp]),
 }
@@ -541,6 +542,25 @@ class AmisCore:
             msg = lib().bild_amis_error(self._h).decode()
             raise RuntimeError(msg) if 'converge' in msg else BildAmdError(code, msg)
         return tuple(ev)
+
+
+def _amis_step_fused(self, model, ts, ss, thetas, path='auto'):
+    """
+    the likelihood of the new batch and the bookkeeping of the step in one native call (bild_amis_step_fused): the samples
+    go up once, nothing but partial sums comes down -> (logev, dlogev, KL)
+    """
+    ss = f64(ss)
+    thetas = np.ascontiguousarray(thetas, dtype=np.int64)
+    assert ss.shape == thetas.shape and ss.shape[1] == self.k1
+    ev = np.empty(3)
+    code = lib().bild_amis_step_fused(self._h, model._h, ts._h, len(ss), dptr(ss), thetas.ctypes.data_as(_vp), PATHS[path], dptr(ev))
+    if code != OK:
+        msg = lib().bild_amis_error(self._h).decode()
+        raise RuntimeError(msg) if 'converge' in msg else BildAmdError(code, msg)
+    return tuple(ev)
+
+
+AmisCore.step_fused = _amis_step_fused
 
 
 def choice_counts(rvs, mu, dmu, dE, omit=None, want_dn=True):

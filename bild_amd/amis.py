@@ -426,10 +426,13 @@ class FixedkSampler:
                  max_fcomplete=1000,
                  native=True,
                  device_bookkeeping=None,
+                 fused=True,
                  ):
         self.k = k
         self.N = N
         self.native = native
+        # with the bookkeeping on the GPU: likelihood and bookkeeping of a step in one native call (`_step_native`)
+        self.fused = fused
         # where the native bookkeeping of a step runs: None = on the GPU for batches of >= 2000 samples per step when there
         # is one (the passes over the pooled samples are then most of a step), else on the host; True / False force it
         self.device_bookkeeping = device_bookkeeping
@@ -748,15 +751,30 @@ class FixedkSampler:
         """
         new_ss = self.dirichlet.sample(a_cur, self.N)
         new_thetas = self._core.sample_traces(np.random.random_sample((self.k + 1, self.N)))
-        new_logLs = self.logL(new_ss, new_thetas)
         self._chunks.append((new_ss, new_thetas))   # pooled on demand (`_pool`): a step itself does not need them
         self._sizes.append(len(new_ss))
-        evidence = self._core.step(new_ss, new_thetas, new_logLs)    # RuntimeError if the CFC fit does not converge
+        if self._fusable():
+            # likelihood and bookkeeping in ONE native call: the samples go up once, the log-likelihoods stay in HBM with
+            # the pooled samples (`_arr` fetches them when somebody looks), a few hundred partial sums come down
+            evidence = self._core.step_fused(self.model.handle(), self.model.trajset(self.traj), new_ss, new_thetas,
+                                             path=self.model.path)
+        else:
+            new_logLs = self.logL(new_ss, new_thetas)
+            evidence = self._core.step(new_ss, new_thetas, new_logLs)    # RuntimeError if the CFC fit does not converge
         self.parameters.append(self._core.params(-1))
         self.evidences.append(evidence)
         if (len(self._sizes) + 1) * self.N >= self.max_fev:
             self.exhausted = True
         return True
+
+    def _fusable(self):
+        """
+        the fused step applies when the pooled samples are on the device, the likelihood is this package's GPU kernel on
+        this very model (not a wrapper around it, not an overridden `logL`) and the lists fit the walk kernel (k + 1 <= 16)
+        """
+        from .models import MultiStateRouse
+        return (getattr(self._core, 'on_device', False) and self.fused and type(self.model) is MultiStateRouse
+                and 'logL' not in self.__dict__ and type(self).logL is FixedkSampler.logL and self.k + 1 <= 16)
 
     # -- summaries ----------------------------------------------------------------------------------
     def tstat(self, other):

@@ -32,9 +32,17 @@ __device__ inline void tree_sum(double *col, int width, int tid)
 }
 
 // samples [lo, hi), `per_lane` consecutive ones per lane; block b writes its partial to row row0 + b
+// what pass A derives for NEW samples that were not prepared on the host (fused step: the samples went up as (s, theta)
+// rows for the likelihood and stay where they are): pointers into the pool, null when the host has prepared them
+struct AmisDerive {
+    const uint8_t *theta8; // P x k1, the states as they went up
+    uint8_t *has_zero;
+    int32_t *first, *pcode, *theta;
+};
+
 __global__ void __launch_bounds__(kAmisBlock) pass_a_kernel(AmisView v, int64_t Q, int64_t P0, int64_t lo, int64_t hi, int per_lane,
                                                             int row0, double logQ, double *log_ss, double *cur, double *logd,
-                                                            double *logw, double *partial)
+                                                            double *logw, double *partial, AmisDerive dv)
 {
     __shared__ double top_s[kAmisBlock];
     __shared__ int nan_s;
@@ -51,9 +59,18 @@ __global__ void __launch_bounds__(kAmisBlock) pass_a_kernel(AmisView v, int64_t 
             ld = amis_logaddexp(logd[p], cq);
         } else {
             // a new sample: its logs first (the host skipped them), as the host takes them: log(0) stays out (0 stands in)
+            bool z = false;
             for (int j = 0; j < v.k1; ++j) {
                 const double sv = v.ss[(size_t)p * v.k1 + j];
+                z |= sv == 0;
                 log_ss[(size_t)p * v.k1 + j] = sv == 0 ? 0.0 : log(sv);
+            }
+            if (dv.theta8 != nullptr) { // ... and what bild_amis_step's host loop derives from the states (amis_host.cpp)
+                const uint8_t *t8 = dv.theta8 + (size_t)p * v.k1;
+                dv.has_zero[p] = z ? 1 : 0;
+                dv.first[p] = t8[0];
+                for (int i = 0; i < v.k1; ++i) dv.theta[(size_t)p * v.k1 + i] = t8[i];
+                for (int i = 0; i < v.k; ++i) dv.pcode[(size_t)p * v.k + i] = (i * v.n + t8[i]) * v.n + t8[i + 1];
             }
             // log-sum-exp over all proposals used so far, as the host's lse(): largest first, NaN if any term is
             double mx = amis_neg_inf();
@@ -147,30 +164,33 @@ __global__ void __launch_bounds__(kAmisBlock) pass_c_kernel(AmisView v, int64_t 
     for (int e = tid; e < width; e += kAmisBlock) partial[(size_t)blockIdx.x * width + e] = col[e * kAmisBlock];
 }
 
-int finish(const char *)
+int finish(hipStream_t st, bool wait)
 {
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    if (e == hipSuccess && wait) e = hipStreamSynchronize(st);
     return e == hipSuccess ? 0 : 1;
 }
 
 } // namespace
 
 int amis_dev_pass_a(const AmisView &v, int64_t Q, int64_t P0, int64_t P, double logQ, double *log_ss, double *cur, double *logd,
-                    double *logw, double *partial, int *rows)
+                    double *logw, double *partial, int *rows, void *stream, const uint8_t *theta8, uint8_t *has_zero, int32_t *first,
+                    int32_t *pcode, int32_t *theta)
 {
+    hipStream_t st = (hipStream_t)stream;
+    const AmisDerive dv{theta8, has_zero, first, pcode, theta};
     // the samples drawn so far: one log-density each, kAmisPerLane per lane; the new ones: all Q proposals each (twice:
     // maximum, then sum) -- one per lane, or ten blocks would work while the rest of the chip looks on
     const int64_t per_block = (int64_t)kAmisBlock * kAmisPerLane;
     const int old_blocks = (int)((P0 + per_block - 1) / per_block), new_blocks = (int)((P - P0 + kAmisBlock - 1) / kAmisBlock);
     if (old_blocks)
-        hipLaunchKernelGGL(pass_a_kernel, dim3(old_blocks), dim3(kAmisBlock), 0, nullptr, v, Q, P0, (int64_t)0, P0, kAmisPerLane, 0, logQ,
-                           log_ss, cur, logd, logw, partial);
+        hipLaunchKernelGGL(pass_a_kernel, dim3(old_blocks), dim3(kAmisBlock), 0, st, v, Q, P0, (int64_t)0, P0, kAmisPerLane, 0, logQ,
+                           log_ss, cur, logd, logw, partial, dv);
     if (new_blocks)
-        hipLaunchKernelGGL(pass_a_kernel, dim3(new_blocks), dim3(kAmisBlock), 0, nullptr, v, Q, P0, P0, P, 1, old_blocks, logQ, log_ss,
-                           cur, logd, logw, partial);
+        hipLaunchKernelGGL(pass_a_kernel, dim3(new_blocks), dim3(kAmisBlock), 0, st, v, Q, P0, P0, P, 1, old_blocks, logQ, log_ss,
+                           cur, logd, logw, partial, dv);
     *rows = old_blocks + new_blocks;
-    return finish("A");
+    return finish(st, false);
 }
 
 int amis_dev_pass_a_rows(int64_t P0, int64_t P)
@@ -180,19 +200,19 @@ int amis_dev_pass_a_rows(int64_t P0, int64_t P)
 }
 
 int amis_dev_pass_b(const AmisView &v, int64_t P, double top, int top_finite, const double *logw, double *rel, double *partial,
-                    int blocks)
+                    int blocks, void *stream)
 {
     const size_t lds = (size_t)(2 + v.k1 + v.n * v.k1) * kAmisBlock * sizeof(double);
-    hipLaunchKernelGGL(pass_b_kernel, dim3(blocks), dim3(kAmisBlock), lds, nullptr, v, P, top, top_finite, logw, rel, partial);
-    return finish("B");
+    hipLaunchKernelGGL(pass_b_kernel, dim3(blocks), dim3(kAmisBlock), lds, (hipStream_t)stream, v, P, top, top_finite, logw, rel, partial);
+    return finish((hipStream_t)stream, false);
 }
 
 int amis_dev_pass_c(const AmisView &v, int64_t P, const double *mean, double ev, const double *rel, const double *cur, double *partial,
-                    int blocks)
+                    int blocks, void *stream)
 {
     const size_t lds = (size_t)(v.k1 + 2) * kAmisBlock * sizeof(double);
-    hipLaunchKernelGGL(pass_c_kernel, dim3(blocks), dim3(kAmisBlock), lds, nullptr, v, P, mean, ev, rel, cur, partial);
-    return finish("C");
+    hipLaunchKernelGGL(pass_c_kernel, dim3(blocks), dim3(kAmisBlock), lds, (hipStream_t)stream, v, P, mean, ev, rel, cur, partial);
+    return finish((hipStream_t)stream, false);
 }
 
 } // namespace bild

@@ -27,6 +27,7 @@
 
 #include "../../include/bild_amd.h"
 #include "amis_math.h"
+#include "internal.h"
 
 namespace {
 
@@ -73,7 +74,9 @@ struct bild_amis {
     int mom_maxiter = 1000;
     double mom_precision = 1e-2;
 
-    int64_t P() const { return (int64_t)logL.size(); }
+    int64_t P() const { return (int64_t)logL.size(); } // samples the HOST holds
+    // all samples: fused steps (bild_amis_step_fused) leave the new ones in HBM only, the host catches up when somebody looks
+    int64_t total() const { return dev.on && dev.P > P() ? dev.P : P(); }
 
     void derive(size_t q)
     {
@@ -136,8 +139,11 @@ struct bild_amis {
         double *ss = nullptr, *log_ss = nullptr, *logL = nullptr, *logd = nullptr, *cur = nullptr, *logw = nullptr, *rel = nullptr;
         uint8_t *has_zero = nullptr;
         int32_t *first = nullptr, *pcode = nullptr, *theta = nullptr;
+        uint8_t *theta8 = nullptr; // fused step: the states as they went up for the likelihood (P x k1)
         double *partial = nullptr, *mean = nullptr;
         int64_t partial_cap = 0;
+        double *partial_host = nullptr; // pinned: the partial sums of a pass on their way down
+        int64_t partial_host_cap = 0;
         void *stage = nullptr; // pinned host memory: the new samples of a step on their way up
         size_t stage_bytes = 0;
     };
@@ -251,10 +257,11 @@ int dev_regrow(bild_amis &m, T *&ptr, size_t old_count, size_t new_count)
 void dev_release(bild_amis::Dev &d)
 {
     void *all[] = {d.a, d.dir_norm, d.head, d.pair, d.ss, d.log_ss, d.logL, d.logd, d.cur, d.logw, d.rel, d.has_zero, d.first,
-                   d.pcode, d.theta, d.partial, d.mean};
+                   d.pcode, d.theta, d.theta8, d.partial, d.mean};
     for (void *q : all)
         if (q) (void)hipFree(q);
     if (d.stage) (void)hipHostFree(d.stage);
+    if (d.partial_host) (void)hipHostFree(d.partial_host);
     d = bild_amis::Dev();
 }
 
@@ -272,7 +279,7 @@ int dev_reserve(bild_amis &m, int64_t P, int64_t Q)
             (rc = dev_regrow(m, d.cur, have, (size_t)cap)) || (rc = dev_regrow(m, d.logw, have, (size_t)cap)) ||
             (rc = dev_regrow(m, d.rel, 0, (size_t)cap)) || (rc = dev_regrow(m, d.has_zero, have, (size_t)cap)) ||
             (rc = dev_regrow(m, d.first, have, (size_t)cap)) || (rc = dev_regrow(m, d.pcode, have * k, cap * std::max<size_t>(k, 1))) ||
-            (rc = dev_regrow(m, d.theta, have * k1, cap * k1)))
+            (rc = dev_regrow(m, d.theta, have * k1, cap * k1)) || (rc = dev_regrow(m, d.theta8, have * k1, cap * k1)))
             return rc;
         d.cap = cap;
     }
@@ -285,6 +292,8 @@ int dev_reserve(bild_amis &m, int64_t P, int64_t Q)
         d.qcap = qcap;
     }
     if (!d.mean) AMIS_HIP(hipMalloc((void **)&d.mean, k1 * sizeof(double)));
+    // (the device-to-device copies of a regrowth ran on the null stream; the passes may run on another one)
+    AMIS_HIP(hipDeviceSynchronize());
     return BILD_OK;
 }
 
@@ -297,7 +306,7 @@ int dev_push(bild_amis &m, bool with_state)
     const int64_t P = m.P(), Q = (int64_t)m.a.size();
     int rc;
     if ((rc = dev_reserve(m, P, Q))) return rc;
-    const size_t lo = (size_t)d.P, cnt = (size_t)(P - d.P);
+    const size_t lo = (size_t)d.P, cnt = P > d.P ? (size_t)(P - d.P) : 0;
     if (cnt) {
         // one pinned staging block, asynchronous copies out of it, one synchronisation (seven synchronous copies out of
         // pageable memory cost 0.2 ms per step)
@@ -347,10 +356,40 @@ int dev_push(bild_amis &m, bool with_state)
 }
 
 // the per-sample results of the device passes, back into the host arrays (exports, a later host-side step)
+// samples that fused steps left in HBM only: the host's copy of the static per-sample data catches up
+int host_catch_up(bild_amis &m)
+{
+    bild_amis::Dev &d = m.dev;
+    if (!d.on || d.P <= m.P()) return BILD_OK;
+    const size_t k1 = m.k1, k = m.k, lo = (size_t)m.P(), P = (size_t)d.P, cnt = P - lo;
+    m.ss.resize(P * k1);
+    m.log_ss.resize(P * k1);
+    m.has_zero.resize(P);
+    m.first.resize(P);
+    m.pcode.resize(P * k);
+    m.theta.resize(P * k1);
+    m.logL.resize(P);
+    m.logd.resize(P);
+    m.cur.resize(P);
+    m.logw.resize(P);
+    AMIS_HIP(hipDeviceSynchronize());
+    AMIS_HIP(hipMemcpy(m.ss.data() + lo * k1, d.ss + lo * k1, cnt * k1 * sizeof(double), hipMemcpyDeviceToHost));
+    AMIS_HIP(hipMemcpy(m.log_ss.data() + lo * k1, d.log_ss + lo * k1, cnt * k1 * sizeof(double), hipMemcpyDeviceToHost));
+    AMIS_HIP(hipMemcpy(m.has_zero.data() + lo, d.has_zero + lo, cnt, hipMemcpyDeviceToHost));
+    AMIS_HIP(hipMemcpy(m.first.data() + lo, d.first + lo, cnt * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (k) AMIS_HIP(hipMemcpy(m.pcode.data() + lo * k, d.pcode + lo * k, cnt * k * sizeof(int32_t), hipMemcpyDeviceToHost));
+    AMIS_HIP(hipMemcpy(m.theta.data() + lo * k1, d.theta + lo * k1, cnt * k1 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    AMIS_HIP(hipMemcpy(m.logL.data() + lo, d.logL + lo, cnt * sizeof(double), hipMemcpyDeviceToHost));
+    m.log_ss_valid = (int64_t)P;
+    d.host_stale = true; // logd / cur / logw of these samples are on the device only
+    return BILD_OK;
+}
+
 int dev_pull(const bild_amis &mc)
 {
     bild_amis &m = const_cast<bild_amis &>(mc);
     bild_amis::Dev &d = m.dev;
+    if (int rc = host_catch_up(m)) return rc;
     if (!d.on || !d.host_stale) return BILD_OK;
     const size_t P = (size_t)std::min<int64_t>(d.P, m.P());
     if (P) {
@@ -380,10 +419,20 @@ bild::AmisView dev_view(const bild_amis &m)
     return v;
 }
 
-int dev_partials(bild_amis &m, int64_t doubles, std::vector<double> &host)
+// the partial sums of the pass just launched on `st`, through pinned memory; waits for the stream
+int dev_partials(bild_amis &m, int64_t doubles, std::vector<double> &host, hipStream_t st)
 {
-    host.resize((size_t)doubles);
-    AMIS_HIP(hipMemcpy(host.data(), m.dev.partial, (size_t)doubles * sizeof(double), hipMemcpyDeviceToHost));
+    bild_amis::Dev &d = m.dev;
+    if (doubles > d.partial_host_cap) {
+        if (d.partial_host) (void)hipHostFree(d.partial_host);
+        d.partial_host = nullptr;
+        d.partial_host_cap = 0;
+        AMIS_HIP(hipHostMalloc((void **)&d.partial_host, (size_t)doubles * 2 * sizeof(double), hipHostMallocDefault));
+        d.partial_host_cap = doubles * 2;
+    }
+    AMIS_HIP(hipMemcpyAsync(d.partial_host, d.partial, (size_t)doubles * sizeof(double), hipMemcpyDeviceToHost, st));
+    AMIS_HIP(hipStreamSynchronize(st));
+    host.assign(d.partial_host, d.partial_host + doubles);
     return BILD_OK;
 }
 
@@ -420,7 +469,7 @@ int bild_amis_destroy(bild_amis *m)
 
 const char *bild_amis_error(const bild_amis *m) { return m ? m->err.c_str() : ""; }
 
-int64_t bild_amis_pool_size(const bild_amis *m) { return m ? m->P() : 0; }
+int64_t bild_amis_pool_size(const bild_amis *m) { return m ? m->total() : 0; }
 int64_t bild_amis_num_proposals(const bild_amis *m) { return m ? (int64_t)m->a.size() : 0; }
 
 int bild_amis_params(const bild_amis *m, int64_t which, double *a, double *logp)
@@ -449,7 +498,7 @@ int bild_amis_pool(const bild_amis *m, int what, double *out)
 int bild_amis_restore(bild_amis *m, int64_t Q_extra, const double *a, const double *logp, int64_t P, const double *ss,
                       const int64_t *thetas, const double *logLs, const double *logd, const double *cur, const double *logw)
 {
-    if (!m || m->P() != 0 || m->a.size() != 1 || Q_extra < 0 || P < 0) return BILD_ERR_INVALID;
+    if (!m || m->total() != 0 || m->a.size() != 1 || Q_extra < 0 || P < 0) return BILD_ERR_INVALID;
     if ((Q_extra && (!a || !logp)) || (P && (!ss || !thetas || !logLs || !logd || !cur || !logw))) return BILD_ERR_INVALID;
     const int k1 = m->k1, k = m->k, n = m->n;
     for (int64_t q = 0; q < Q_extra; ++q) {
@@ -572,12 +621,26 @@ int bild_amis_use_device(bild_amis *m, int enable)
 // One AMIS iteration after the likelihood of the new batch is known (amis.py:819-906).
 // evidence[3] = (logev, dlogev, KL).  Returns BILD_ERR_INVALID with "Iteration did not converge" in
 // bild_amis_error when the CFC fit does not converge (the reference raises RuntimeError there).
-int bild_amis_step(bild_amis *m, int64_t N, const double *ss, const int64_t *thetas, const double *logLs, double *evidence)
+// `model` given: the FUSED step -- the new samples go up once, as the (s, theta) rows the likelihood kernels read
+// (walk.hip), into the pool where the passes below find them; their likelihood is written into the pool by the kernels;
+// what the host loop of the plain step derives per sample (has_zero, first, pcode) is derived by pass A on the device; and
+// everything runs on the model's stream, so the only synchronisations are the three copies of partial sums.  The host's
+// copy of the pool catches up when somebody asks for it (host_catch_up).
+static int amis_step_impl(bild_amis *m, int64_t N, const double *ss, const int64_t *thetas, const double *logLs, double *evidence,
+                          const bild_model *model, const bild_trajset *ts, unsigned flags)
 {
-    if (!m || !ss || !thetas || !logLs || !evidence || N < 1) return BILD_ERR_INVALID;
+    const bool fused = model != nullptr;
+    if (!m || !ss || !thetas || (!fused && !logLs) || !evidence || N < 1) return BILD_ERR_INVALID;
+    if (fused && (!m->dev.on || !ts)) {
+        m->err = "fused step: the pooled samples must be on the device (bild_amis_use_device)";
+        return BILD_ERR_INVALID;
+    }
+    if (!fused)
+        if (int rc = host_catch_up(*m)) return rc; // (earlier fused steps)
     const int k1 = m->k1, k = m->k, n = m->n;
     const size_t Q = m->a.size(); // proposals used so far, the current one last
-    const int64_t P0 = m->P();
+    const int64_t P0 = m->total();
+    hipStream_t st = nullptr;
     for (int64_t r = 0; r < N; ++r)
         for (int i = 0; i < k1; ++i)
             if (thetas[(size_t)r * k1 + i] < 0 || thetas[(size_t)r * k1 + i] >= n) {
@@ -596,6 +659,49 @@ int bild_amis_step(bild_amis *m, int64_t N, const double *ss, const int64_t *the
     };
     // 2. the new samples and their own denominators: all proposals used so far
     const int64_t P = P0 + N;
+    if (fused) {
+        bild_amis::Dev &d = m->dev;
+        int rc;
+        if ((rc = dev_push(*m, false))) return rc; // proposals not yet mirrored (and room for them)
+        if ((rc = dev_reserve(*m, P, (int64_t)Q))) return rc;
+        const size_t nseg = (size_t)N * k1, need = nseg * sizeof(double) + ((nseg + 15) & ~(size_t)15) + 64;
+        if (need > d.stage_bytes) {
+            if (d.stage) (void)hipHostFree(d.stage);
+            d.stage = nullptr;
+            d.stage_bytes = 0;
+            if (hipHostMalloc(&d.stage, need * 2, hipHostMallocDefault) != hipSuccess) {
+                m->err = "fused step: out of pinned memory";
+                return BILD_ERR_NOMEM;
+            }
+            d.stage_bytes = need * 2;
+        }
+        std::memcpy(d.stage, ss, nseg * sizeof(double));
+        uint8_t *t8 = (uint8_t *)d.stage + nseg * sizeof(double);
+        int32_t *status = (int32_t *)(t8 + ((nseg + 15) & ~(size_t)15));
+        status[0] = status[1] = 0;
+        for (size_t i = 0; i < nseg; ++i) t8[i] = (uint8_t)thetas[i]; // (range checked above)
+        lap("[amis step fused] stage");
+        // everything of this step goes to the model's own stream: the copies, the likelihood, the passes
+        void *stream = bild::internal_model_stream(model);
+        if (!stream) {
+            m->err = bild_last_error();
+            return BILD_ERR_HIP;
+        }
+        st = (hipStream_t)stream;
+        if (hipMemcpyAsync(d.ss + (size_t)P0 * k1, d.stage, nseg * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(d.theta8 + (size_t)P0 * k1, t8, nseg, hipMemcpyHostToDevice, st) != hipSuccess) {
+            m->err = "fused step: upload failed";
+            return BILD_ERR_HIP;
+        }
+        rc = bild::internal_logl_st_resident(model, ts, N, k1, d.ss + (size_t)P0 * k1, d.theta8 + (size_t)P0 * k1, flags, d.logL + P0,
+                                             status, &stream);
+        if (rc) {
+            (void)hipStreamSynchronize(st);
+            m->err = bild_last_error();
+            return rc;
+        }
+        lap("likelihood enqueued");
+    } else {
     m->ss.insert(m->ss.end(), ss, ss + (size_t)N * k1);
     m->log_ss.resize((size_t)P * k1);
     m->has_zero.resize(P);
@@ -622,6 +728,7 @@ int bild_amis_step(bild_amis *m, int64_t N, const double *ss, const int64_t *the
     }
     if (!m->dev.on) m->log_ss_valid = P;
     lap("[amis step] append");
+    }
     const int64_t nchunks = (P + kChunk - 1) / kChunk;
     const double logQ = std::log((double)Q);
     const int nm = n * k1;
@@ -632,8 +739,10 @@ int bild_amis_step(bild_amis *m, int64_t N, const double *ss, const int64_t *the
         // ---- the three passes on the device (amis_device.hip), partial sums added here in block order ----------------
         bild_amis &mm = *m;
         int rc;
-        if ((rc = dev_push(mm, false))) return rc;
-        lap("upload");
+        if (!fused) {
+            if ((rc = dev_push(mm, false))) return rc;
+            lap("upload");
+        }
         const int blocks = (int)((P + (int64_t)bild::kAmisBlock * bild::kAmisPerLane - 1) / ((int64_t)bild::kAmisBlock * bild::kAmisPerLane));
         const int rows_a = bild::amis_dev_pass_a_rows(P0, P);
         const int64_t need = std::max<int64_t>((int64_t)blocks * (2 + k1 + nm), (int64_t)rows_a * 2);
@@ -649,12 +758,23 @@ int bild_amis_step(bild_amis *m, int64_t N, const double *ss, const int64_t *the
         const bild::AmisView dv = dev_view(*m);
         std::vector<double> part;
         int rows = 0;
-        if (bild::amis_dev_pass_a(dv, (int64_t)Q, P0, P, logQ, m->dev.log_ss, m->dev.cur, m->dev.logd, m->dev.logw, m->dev.partial, &rows)) {
+        bild_amis::Dev &d = m->dev;
+        if (bild::amis_dev_pass_a(dv, (int64_t)Q, P0, P, logQ, d.log_ss, d.cur, d.logd, d.logw, d.partial, &rows, (void *)st,
+                                  fused ? d.theta8 : nullptr, d.has_zero, d.first, d.pcode, d.theta)) {
             m->err = "device bookkeeping: pass A failed";
             return BILD_ERR_HIP;
         }
         m->dev.host_stale = true;
-        if ((rc = dev_partials(mm, (int64_t)rows * 2, part))) return rc;
+        if ((rc = dev_partials(mm, (int64_t)rows * 2, part, st))) return rc;
+        if (fused) {
+            // the stream has been waited for: the likelihood's verdict on the rows is in, and the samples are pooled
+            const int32_t *status = (const int32_t *)((uint8_t *)d.stage + (size_t)N * k1 * sizeof(double) + (((size_t)N * k1 + 15) & ~(size_t)15));
+            if (status[0] != 0) {
+                m->err = "interval lengths of a sample are not non-negative finite numbers (of a point on the simplex)";
+                return BILD_ERR_INVALID;
+            }
+            d.P = P;
+        }
         bool nan_w = false;
         for (int b = 0; b < rows; ++b) {
             top = std::max(top, part[(size_t)2 * b]);
@@ -663,12 +783,12 @@ int bild_amis_step(bild_amis *m, int64_t N, const double *ss, const int64_t *the
         if (nan_w) top = std::numeric_limits<double>::quiet_NaN(); // as np.max
         const bool top_finite = std::isfinite(top);
         lap("A");
-        if (bild::amis_dev_pass_b(dv, P, top, top_finite ? 1 : 0, m->dev.logw, m->dev.rel, m->dev.partial, blocks)) {
+        if (bild::amis_dev_pass_b(dv, P, top, top_finite ? 1 : 0, m->dev.logw, m->dev.rel, m->dev.partial, blocks, (void *)st)) {
             m->err = "device bookkeeping: pass B failed";
             return BILD_ERR_HIP;
         }
         const int wb = 2 + k1 + nm;
-        if ((rc = dev_partials(mm, (int64_t)blocks * wb, part))) return rc;
+        if ((rc = dev_partials(mm, (int64_t)blocks * wb, part, st))) return rc;
         for (int b = 0; b < blocks; ++b) {
             const double *row = part.data() + (size_t)b * wb;
             W += row[0];
@@ -679,13 +799,13 @@ int bild_amis_step(bild_amis *m, int64_t N, const double *ss, const int64_t *the
         for (int j = 0; j < k1; ++j) mean[j] /= W;
         ev = sum / (double)P;
         lap("B");
-        if (hipMemcpy(m->dev.mean, mean.data(), (size_t)k1 * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
-            bild::amis_dev_pass_c(dv, P, m->dev.mean, ev, m->dev.rel, m->dev.cur, m->dev.partial, blocks)) {
+        if (hipMemcpyAsync(m->dev.mean, mean.data(), (size_t)k1 * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
+            bild::amis_dev_pass_c(dv, P, m->dev.mean, ev, m->dev.rel, m->dev.cur, m->dev.partial, blocks, (void *)st)) {
             m->err = "device bookkeeping: pass C failed";
             return BILD_ERR_HIP;
         }
         const int wc = k1 + 2;
-        if ((rc = dev_partials(mm, (int64_t)blocks * wc, part))) return rc;
+        if ((rc = dev_partials(mm, (int64_t)blocks * wc, part, st))) return rc;
         for (int b = 0; b < blocks; ++b) {
             const double *row = part.data() + (size_t)b * wc;
             for (int j = 0; j < k1; ++j) var[j] += row[j];
@@ -881,6 +1001,18 @@ int bild_amis_step(bild_amis *m, int64_t N, const double *ss, const int64_t *the
     m->steps += 1;
     m->err.clear();
     return BILD_OK;
+}
+
+int bild_amis_step(bild_amis *m, int64_t N, const double *ss, const int64_t *thetas, const double *logLs, double *evidence)
+{
+    return amis_step_impl(m, N, ss, thetas, logLs, evidence, nullptr, nullptr, 0);
+}
+
+int bild_amis_step_fused(bild_amis *m, const bild_model *model, const bild_trajset *ts, int64_t N, const double *ss,
+                         const int64_t *thetas, unsigned flags, double *evidence)
+{
+    if (!model || !ts) return BILD_ERR_INVALID;
+    return amis_step_impl(m, N, ss, thetas, nullptr, evidence, model, ts, flags);
 }
 
 // Choice of the next k in the adaptive-k loop (reference bild/choicesampler.py:115-210): for every row of the

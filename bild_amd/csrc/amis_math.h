@@ -83,17 +83,20 @@ BILD_HD inline double amis_rel_weight(double logw, double top)
 }
 
 // ---- device passes (amis_device.hip; stubs in asan_stubs.cpp).  All buffers device memory; `partial` holds one row of
-// `width` doubles per block; launches go to the null stream and the functions return after the results are on the host.
+// `width` doubles per block.
 struct AmisDeviceOut; // host-side staging owned by amis_host.cpp
 constexpr int kAmisBlock = 64;        // lanes per block (one accumulator column in LDS per lane)
 constexpr int kAmisPerLane = 16;      // samples per lane
 constexpr int kAmisMaxNm = 64;        // n * k1 the device passes support
 int amis_dev_pass_a_rows(int64_t P0, int64_t P); // rows of `partial` pass A writes
+// (the launches go to `stream`, a hipStream_t; nothing is waited for: the caller's copy of `partial` does that.  theta8 ...
+// theta: see AmisDerive in amis_device.hip -- null when the host has prepared the new samples)
 int amis_dev_pass_a(const AmisView &v, int64_t Q, int64_t P0, int64_t P, double logQ, double *log_ss /* = v.log_ss: written for the new samples */,
-                    double *cur, double *logd, double *logw, double *partial /* rows x 2: max, any NaN */, int *rows);
+                    double *cur, double *logd, double *logw, double *partial /* rows x 2: max, any NaN */, int *rows, void *stream,
+                    const uint8_t *theta8, uint8_t *has_zero, int32_t *first, int32_t *pcode, int32_t *theta);
 int amis_dev_pass_b(const AmisView &v, int64_t P, double top, int top_finite, const double *logw, double *rel,
-                    double *partial /* blocks x (2 + k1 + n k1): W, S, acc, marg */, int blocks);
+                    double *partial /* blocks x (2 + k1 + n k1): W, S, acc, marg */, int blocks, void *stream);
 int amis_dev_pass_c(const AmisView &v, int64_t P, const double *mean /* k1, device */, double ev, const double *rel, const double *cur,
-                    double *partial /* blocks x (k1 + 2): var, sq, kl */, int blocks);
+                    double *partial /* blocks x (k1 + 2): var, sq, kl */, int blocks, void *stream);
 
 } // namespace bild

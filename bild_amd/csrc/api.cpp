@@ -21,6 +21,7 @@
 #include "../../include/bild_amd.h"
 #include "common.h"
 #include "host_linalg.h"
+#include "internal.h"
 
 using namespace bild;
 using la::Mat;
@@ -1427,6 +1428,43 @@ int run_staged(const bild_model *m, const bild_trajset *ts, int64_t n, int K1, c
 }
 
 } // namespace
+
+void *bild::internal_model_stream(const bild_model *m)
+{
+    if (!m || ensure_device(*m) != BILD_OK) return nullptr;
+    return (void *)m->stream;
+}
+
+// (s, theta) rows that are resident in HBM already (internal.h): the fused AMIS step (amis_host.cpp) keeps its pooled samples
+// there and hands the newest batch over where it lies
+int bild::internal_logl_st_resident(const bild_model *m, const bild_trajset *ts, int64_t n, int K1, const double *d_ss,
+                                    const uint8_t *d_thetas, unsigned flags, double *d_out, int32_t *status, void **stream)
+{
+    if (!m || !ts || ts->model != m || n < 1 || K1 < 1 || K1 > kSplitMaxK1 || !d_ss || !d_thetas || !d_out || !status)
+        return fail(BILD_ERR_INVALID, "internal_logl_st_resident: bad arguments");
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev != ts->device) return fail(BILD_ERR_INVALID, "trajectory set lives on device %d, current device is %d", ts->device, dev);
+    std::lock_guard<std::mutex> call_lock(m->call_mu);
+    if (m->h_in_busy) HIP_TRY(hipEventSynchronize(m->h_in_event));
+    m->h_in_busy = false;
+    const size_t nseg = (size_t)n * K1;
+    {
+        std::lock_guard<std::mutex> lk(m->mu);
+        if (int rc = m->ws_in.reserve(2 * nseg * sizeof(int32_t))) return rc;
+    }
+    int32_t *d_start = (int32_t *)m->ws_in.ptr, *d_state = d_start + nseg; // the lists the walk kernel writes for the frame loop
+    SplitIn sp;
+    sp.d_ss = d_ss;
+    sp.d_thetas = (const int8_t *)d_thetas;
+    sp.status = status;
+    if (stream) *stream = (void *)m->stream;
+    int rc = launch_batch(*m, *ts, n, K1, d_start, d_state, nullptr, nullptr, flags, m->stream, d_out, &sp);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(m->h_in_event, m->stream)); // (the next host-buffer call must not reuse the lists before this one is through)
+    m->h_in_busy = true;
+    return BILD_OK;
+}
 
 // ------------------------------------------------------------------------------------
 // exported

@@ -4,6 +4,7 @@
 // only as far as packing needs them (padded_rows), with the same values as kernels.hip.
 #include "common.h"
 #include "amis_math.h"
+#include "internal.h"
 
 namespace bild {
 int padded_rows(int n)
@@ -30,7 +31,9 @@ int device_schedule(const int32_t *, const int32_t *, const TrajDesc *, int, int
 int launch_logl_wide(int, const KParams &, int, void *) { return 1; }
 int launch_walk(const WalkParams &, void *) { return 1; }
 int amis_dev_pass_a_rows(int64_t, int64_t) { return 0; }
-int amis_dev_pass_a(const AmisView &, int64_t, int64_t, int64_t, double, double *, double *, double *, double *, double *, int *) { return 1; }
-int amis_dev_pass_b(const AmisView &, int64_t, double, int, const double *, double *, double *, int) { return 1; }
-int amis_dev_pass_c(const AmisView &, int64_t, const double *, double, const double *, const double *, double *, int) { return 1; }
+int amis_dev_pass_a(const AmisView &, int64_t, int64_t, int64_t, double, double *, double *, double *, double *, double *, int *, void *, const uint8_t *, uint8_t *, int32_t *, int32_t *, int32_t *) { return 1; }
+int amis_dev_pass_b(const AmisView &, int64_t, double, int, const double *, double *, double *, int, void *) { return 1; }
+int amis_dev_pass_c(const AmisView &, int64_t, const double *, double, const double *, const double *, double *, int, void *) { return 1; }
+void *internal_model_stream(const bild_model *) { return nullptr; }
+int internal_logl_st_resident(const bild_model *, const bild_trajset *, int64_t, int, const double *, const uint8_t *, unsigned, double *, int32_t *, void **) { return 1; }
 } // namespace bild

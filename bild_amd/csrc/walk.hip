@@ -98,20 +98,19 @@ __device__ __forceinline__ int walk_task(const WalkParams &p, const int64_t task
             }
         }
     }
+    // (every chain of a candidate that goes on to the frame loop writes the candidate's list: the same values)
     auto write_list = [&]() {
         if constexpr (ST) {
-            if (e == 0) {
 #pragma unroll
-                for (int i = 0; i < KMAX; ++i)
-                    if (i < K1) {
-                        p.seg_out_start[r * K1 + i] = a[i];
-                        p.seg_out_state[r * K1 + i] = b[i];
-                    }
-            }
+            for (int i = 0; i < KMAX; ++i)
+                if (i < K1) {
+                    p.seg_out_start[r * K1 + i] = a[i];
+                    p.seg_out_state[r * K1 + i] = b[i];
+                }
         }
     };
     if (p.convert_all) {
-        write_list();
+        if (e == 0) write_list();
         return -1;
     }
     if (e >= td->dstar) {

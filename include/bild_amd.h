@@ -367,6 +367,13 @@ int bild_amis_sample_traces(const bild_amis *m, int64_t N, const double *u, int6
  * bild_amis_error() == "Iteration did not converge" (the reference raises RuntimeError) */
 int bild_amis_step(bild_amis *m, int64_t N, const double *ss, const int64_t *thetas,
                    const double *logLs, double *evidence);
+/* The fused step (pooled samples on the device, see bild_amis_use_device below; K1 = k + 1 <= 16): the new samples go up
+ * ONCE, as the (s, theta) rows the likelihood kernels read, straight into the pool; their log-likelihood on `ts` (one
+ * trajectory) is computed there (as bild_logl_st would) and written into the pool; the passes over the pool follow on the
+ * same stream.  Nothing but a few hundred partial sums comes down; the host's copy of the pool (bild_amis_pool) catches up
+ * when it is asked for.  Same results as bild_logl_st followed by bild_amis_step. */
+int bild_amis_step_fused(bild_amis *m, const bild_model *model, const bild_trajset *ts, int64_t N,
+                         const double *ss, const int64_t *thetas, unsigned flags, double *evidence);
 /* keep the pooled samples in HBM and run the passes of bild_amis_step over them on the GPU (enable != 0), or return
  * to the host implementation (0).  Same arithmetic per sample (csrc/amis_math.h); sums are formed per block in a fixed
  * order, so results are reproducible and agree with the host's to rounding.  For batches of thousands of samples per

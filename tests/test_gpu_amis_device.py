@@ -141,3 +141,62 @@ def test_zeros_poles_and_impossible_traces(built_lib):
         with pytest.raises(RuntimeError):
             core.step(ss, thetas, logLs)
     compare()                                               # samples appended on both sides, no new proposal
+
+
+def _rouse_sampler(seed, fused, N=3000, k=3, T=300, steps=4, **kw):
+    import bild_amd
+    import helpers as H
+    rng = np.random.default_rng(seed)
+    model = bild_amd.MultiStateRouse(20, 1, 5, d=3, localization_error=0.1)
+    traj = model.trajectory_from_loopingprofile(H.random_profile(rng, T, 2, T // 5), rng=rng)
+    np.random.seed(seed)
+    s = bild_amd.FixedkSampler(traj, model, k=k, N=N, max_fev=10 ** 9, max_fcomplete=0, fused=fused, **kw)
+    for _ in range(steps):
+        s.step()
+    return s
+
+
+def test_fused_step_equals_likelihood_call_plus_bookkeeping(built_lib):
+    """
+    bild_amis_step_fused: the new samples go up once, as the (s, theta) rows the likelihood kernels read, into the pool in
+    HBM; their log-likelihoods are written there; pass A derives on the device what the plain step derives on the host.
+    Same kernels, same arithmetic, same order of the sums: every evidence, every proposal and every pooled array equals the
+    run that calls `logL` and `bild_amis_step` separately -- bit for bit.  Then a plain step behind fused ones (the host's
+    copy of the pool catches up first), a pickled sampler, and MAP / marginals, which read the pool.
+    """
+    import bild_amd
+    fused, plain = _rouse_sampler(5, True), _rouse_sampler(5, False)
+    assert fused._core.on_device and fused._fusable() and not plain._fusable()
+    assert len(fused._core) == len(plain._core) == 4 * 3000
+    assert np.array_equal(np.array(fused.evidences), np.array(plain.evidences))
+    for (a0, l0), (a1, l1) in zip(fused.parameters, plain.parameters):
+        assert np.array_equal(a0, a1) and np.array_equal(l0, l1)
+    for key in fused._core.POOL:
+        assert np.array_equal(fused._core.pool(key), plain._core.pool(key)), key
+    assert np.array_equal(fused.MAP_profile()[:], plain.MAP_profile()[:])
+    assert np.array_equal(fused.log_marginal_posterior(), plain.log_marginal_posterior())
+    # a plain step behind fused ones, and a fused one behind that
+    state = np.random.get_state()
+    fused.fused = False
+    fused.step()
+    fused.fused = True
+    fused.step()
+    np.random.set_state(state)
+    plain.step()
+    plain.step()
+    assert np.array_equal(np.array(fused.evidences), np.array(plain.evidences))
+    assert np.array_equal(fused._core.pool('log_weights'), plain._core.pool('log_weights'))
+    # pickling reads the whole pool back
+    clone = pickle.loads(pickle.dumps(fused))
+    state = np.random.get_state()
+    clone.step()
+    np.random.set_state(state)
+    fused.step()
+    assert np.allclose(np.array(clone.evidences[-1]), np.array(fused.evidences[-1]), rtol=1e-10, atol=1e-10)
+    # rows that are no points on the simplex are refused, as by `logL`
+    bad = bild_amd.FixedkSampler(fused.traj, fused.model, k=3, N=3000, max_fev=10 ** 9, max_fcomplete=0)
+    ss = np.random.dirichlet(np.ones(4), size=3000)
+    ss[17, 2] = np.nan
+    th = bad._core.sample_traces(np.random.random_sample((4, 3000)))
+    with pytest.raises(Exception):
+        bad._core.step_fused(bad.model.handle(), bad.model.trajset(bad.traj), ss, th)
