@@ -95,6 +95,8 @@ _SIGNATURES = {
     'bild_amis_step': (ctypes.c_int, [_vp, ctypes.c_int64, _dp, _vp, _dp, _dp]),
     'bild_amis_use_device': (ctypes.c_int, [_vp, ctypes.c_int]),
     'bild_amis_step_fused': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, _dp, _vp, ctypes.c_uint, _dp]),
+    'bild_amis_step_device_rng': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint, _dp]),
+    'bild_amis_pool_samples': (ctypes.c_int, [_vp, _dp, _vp]),
     'bild_interval_marginals': (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int64, _ip, _ip, _dp, _dp]),
     'bild_choice_counts': (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, _dp, _dp, _dp, ctypes.c_double, _vp, _vp, _vp, _vp]),
 }
@@ -561,6 +563,29 @@ def _amis_step_fused(self, model, ts, ss, thetas, path='auto'):
 
 
 AmisCore.step_fused = _amis_step_fused
+
+
+def _amis_step_device_rng(self, model, ts, N, seed, path='auto'):
+    """ a fused step whose samples are drawn on the device (bild_amis_step_device_rng) -> (logev, dlogev, KL) """
+    ev = np.empty(3)
+    code = lib().bild_amis_step_device_rng(self._h, model._h, ts._h, int(N), ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), PATHS[path], dptr(ev))
+    if code != OK:
+        msg = lib().bild_amis_error(self._h).decode()
+        raise RuntimeError(msg) if 'converge' in msg else BildAmdError(code, msg)
+    return tuple(ev)
+
+
+def _amis_pool_samples(self):
+    """ (ss, thetas) of all pooled samples, fetched from the device where fused steps left them """
+    P = len(self)
+    ss, thetas = np.empty((P, self.k1)), np.empty((P, self.k1), dtype=np.int64)
+    if lib().bild_amis_pool_samples(self._h, dptr(ss), thetas.ctypes.data_as(_vp)) != OK:
+        raise BildAmdError(ERR_HIP, lib().bild_amis_error(self._h).decode())
+    return ss, thetas
+
+
+AmisCore.step_device_rng = _amis_step_device_rng
+AmisCore.pool_samples = _amis_pool_samples
 
 
 def choice_counts(rvs, mu, dmu, dE, omit=None, want_dn=True):

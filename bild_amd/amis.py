@@ -19,6 +19,7 @@ simplex, ``theta`` (k+1,) the state of each interval; neighbouring states obey t
 ``transitions`` matrix.
 """
 import itertools
+import os
 import math
 
 import numpy as np
@@ -83,6 +84,8 @@ class Dirichlet:
         """ (N, k+1) draws (bild/amis.py:66-81) """
         a = np.asarray(a, dtype=np.float64)
         ss = np.random.dirichlet(a, size=N)   # the call scipy.stats.dirichlet.rvs makes
+        if np.isfinite(ss.sum()):             # (a NaN or Inf anywhere shows in the sum: one pass instead of three)
+            return ss
         bad = ~np.all(np.isfinite(ss), axis=1)
         if np.any(bad):
             # All concentrations tiny (a bimodal posterior at the corners of the simplex drives their sum towards
@@ -427,12 +430,24 @@ class FixedkSampler:
                  native=True,
                  device_bookkeeping=None,
                  fused=True,
+                 rng='numpy',
+                 seed=None,
                  ):
         self.k = k
         self.N = N
         self.native = native
         # with the bookkeeping on the GPU: likelihood and bookkeeping of a step in one native call (`_step_native`)
         self.fused = fused
+        # 'numpy' (default): the reference's random stream -- the global NumPy generator, consumed in the reference's order
+        # (bild/amis.py:831-832).  'device': the samples of a step are drawn on the GPU from a counter-based generator keyed
+        # by `seed` (csrc/amis_device.hip: draw_kernel) -- the same sampler in distribution, not the same random numbers;
+        # applies where the fused step does (`_fusable`), else the NumPy stream is used.
+        if rng not in ('numpy', 'device'):
+            raise ValueError("rng must be 'numpy' or 'device'")
+        self.rng = rng
+        # (a default seed must not come out of the global NumPy stream: that stream is the reference's)
+        self.seed = int.from_bytes(os.urandom(8), 'little') if seed is None else int(seed)
+        self._device_drawn = 0      # pooled samples the device drew (the host fetches them when somebody looks)
         # where the native bookkeeping of a step runs: None = on the GPU for batches of >= 2000 samples per step when there
         # is one (the passes over the pooled samples are then most of a step), else on the host; True / False force it
         self.device_bookkeeping = device_bookkeeping
@@ -523,6 +538,10 @@ class FixedkSampler:
     @property
     def _pool(self):
         """ pooled samples ('ss', 'thetas' [, lookup data of the NumPy path]); pending chunks are appended on access """
+        if getattr(self, '_device_drawn', 0) and (self._pool_np is None or len(self._pool_np['ss']) != len(self._core)):
+            ss, thetas = self._core.pool_samples()      # drawn on the device: fetched now
+            self._pool_np = {'ss': ss, 'thetas': thetas}
+            return self._pool_np
         if self._chunks:
             parts_ss = ([self._pool_np['ss']] if self._pool_np else []) + [c[0] for c in self._chunks]
             parts_th = ([self._pool_np['thetas']] if self._pool_np else []) + [c[1] for c in self._chunks]
@@ -749,6 +768,18 @@ class FixedkSampler:
         first state of every trace (one uniform number each), then ``np.random.rand(N, 1)`` per later slot --
         as one block, which is the same stream.
         """
+        if self.rng == 'device' and self._fusable() and not self._chunks and (self._pool_np is None or self._device_drawn):
+            # draws, likelihood and bookkeeping on the device: nothing goes up but the proposal, nothing comes down but
+            # partial sums; the samples are fetched when somebody looks (`_pool`)
+            evidence = self._core.step_device_rng(self.model.handle(), self.model.trajset(self.traj), self.N, self.seed,
+                                                  path=self.model.path)
+            self._device_drawn += self.N
+            self._sizes.append(self.N)
+            self.parameters.append(self._core.params(-1))
+            self.evidences.append(evidence)
+            if (len(self._sizes) + 1) * self.N >= self.max_fev:
+                self.exhausted = True
+            return True
         new_ss = self.dirichlet.sample(a_cur, self.N)
         new_thetas = self._core.sample_traces(np.random.random_sample((self.k + 1, self.N)))
         self._chunks.append((new_ss, new_thetas))   # pooled on demand (`_pool`): a step itself does not need them

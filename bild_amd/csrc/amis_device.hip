@@ -164,6 +164,150 @@ __global__ void __launch_bounds__(kAmisBlock) pass_c_kernel(AmisView v, int64_t 
     for (int e = tid; e < width; e += kAmisBlock) partial[(size_t)blockIdx.x * width + e] = col[e * kAmisBlock];
 }
 
+// ---- drawing the samples of a step on the device (opt-in: FixedkSampler(rng='device')) -----------------------------------
+// The reference draws from NumPy's global stream (scipy.stats.dirichlet.rvs, np.random.choice, np.random.rand:
+// bild/amis.py:66-81, 223-256), and so does this package by default -- 1.0 of the 1.8 ms of a step at N = 10 000.  This is
+// the same distribution from a counter-based generator: Philox-4x32-10 keyed by the sampler's seed, one stream per
+// (step, sample); gamma variates by Marsaglia-Tsang (with the boost gamma(a) = gamma(a + 1) U^(1/a) below one), the
+// Dirichlet point as their normalised vector, the trace slot by slot from the CFC weights as bild_amis_sample_traces does.
+// Not the reference's random numbers -- the same sampler in distribution (tests: evidences agree within their errors).
+struct Philox {
+    uint32_t c[4], k[2];
+    uint32_t out[4];
+    int have;
+    __device__ Philox(uint64_t seed, uint64_t step, uint64_t sample)
+    {
+        c[0] = (uint32_t)sample;
+        c[1] = (uint32_t)(sample >> 32);
+        c[2] = (uint32_t)step;
+        c[3] = 0; // block counter of this stream
+        k[0] = (uint32_t)seed;
+        k[1] = (uint32_t)(seed >> 32);
+        have = 0;
+    }
+    __device__ void block()
+    {
+        uint32_t x0 = c[0], x1 = c[1], x2 = c[2], x3 = c[3], k0 = k[0], k1 = k[1];
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            const uint64_t p0 = (uint64_t)0xD2511F53u * x0, p1 = (uint64_t)0xCD9E8D57u * x2;
+            const uint32_t y0 = (uint32_t)(p1 >> 32) ^ x1 ^ k0, y1 = (uint32_t)p1, y2 = (uint32_t)(p0 >> 32) ^ x3 ^ k1, y3 = (uint32_t)p0;
+            x0 = y0;
+            x1 = y1;
+            x2 = y2;
+            x3 = y3;
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+        out[0] = x0;
+        out[1] = x1;
+        out[2] = x2;
+        out[3] = x3;
+        ++c[3];
+        have = 2;
+    }
+    // uniform in [0, 1) with 53 random bits
+    __device__ double uniform()
+    {
+        if (!have) block();
+        --have;
+        const uint64_t bits = ((uint64_t)out[2 * have] << 32) | out[2 * have + 1];
+        return (double)(bits >> 11) * 0x1p-53;
+    }
+    __device__ double normal() // Box-Muller, one of the pair
+    {
+        const double u1 = 1.0 - uniform(), u2 = uniform(); // u1 in (0, 1]
+        return sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
+    }
+    __device__ double gamma(double a)
+    {
+        if (!(a > 0)) return 0.0;
+        double boost = 1.0;
+        if (a < 1.0) { // gamma(a) = gamma(a + 1) U^(1/a)
+            boost = pow(1.0 - uniform(), 1.0 / a);
+            a += 1.0;
+        }
+        const double d = a - 1.0 / 3.0, cc = 1.0 / sqrt(9.0 * d);
+        for (int it = 0; it < 64; ++it) { // (acceptance > 95 % per trial)
+            const double x = normal(), t = 1.0 + cc * x;
+            if (t <= 0) continue;
+            const double v = t * t * t, u = 1.0 - uniform();
+            if (u < 1.0 - 0.0331 * (x * x) * (x * x) || log(u) < 0.5 * x * x + d * (1.0 - v + log(v))) return boost * d * v;
+        }
+        return boost * d;
+    }
+};
+
+// one sample per lane: ss (N x k1) and the states (N x k1 bytes) written where the likelihood and the passes read them
+__global__ void __launch_bounds__(256) draw_kernel(int k1, int n, int64_t N, uint64_t seed, uint64_t step, const double *__restrict__ a,
+                                                   const double *__restrict__ prob /* n x k1, [state][slot], normalised per slot */,
+                                                   const uint8_t *__restrict__ trans, double *__restrict__ ss, uint8_t *__restrict__ theta8)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= N) return;
+    Philox rng(seed, step, (uint64_t)r);
+    double *row = ss + (size_t)r * k1;
+    double tot = 0, asum = 0;
+    for (int j = 0; j < k1; ++j) {
+        const double g = rng.gamma(a[j]);
+        row[j] = g;
+        tot += g;
+        asum += a[j];
+    }
+    if (tot > 0 && tot < HUGE_VAL) {
+        for (int j = 0; j < k1; ++j) row[j] /= tot;
+    } else {
+        // all concentrations tiny: every variate underflows.  The distribution is then, to all digits, a mixture of point
+        // masses at the corners of the simplex with probabilities a_j / sum(a) (as Dirichlet.sample on the host, amis.py)
+        const double u = rng.uniform() * asum;
+        double c = 0;
+        int corner = k1 - 1;
+        for (int j = 0; j < k1; ++j) {
+            c += a[j];
+            if (u < c) {
+                corner = j;
+                break;
+            }
+        }
+        for (int j = 0; j < k1; ++j) row[j] = j == corner ? 1.0 : 0.0;
+    }
+    // the trace (bild_amis_sample_traces: first state from the slot-0 weights, later ones from the allowed successors)
+    uint8_t *th = theta8 + (size_t)r * k1;
+    int prev;
+    {
+        double last = 0;
+        for (int s = 0; s < n; ++s) last += prob[(size_t)s * k1];
+        const double u = rng.uniform();
+        double c = 0;
+        int idx = n - 1;
+        for (int s = 0; s < n; ++s) {
+            c += prob[(size_t)s * k1];
+            if (c / last > u) {
+                idx = s;
+                break;
+            }
+        }
+        th[0] = (uint8_t)idx;
+        prev = idx;
+    }
+    for (int i = 1; i < k1; ++i) {
+        double last = 0;
+        for (int s = 0; s < n; ++s) last += prob[(size_t)s * k1 + i] * (trans[(size_t)prev * n + s] ? 1.0 : 0.0);
+        const double u = rng.uniform();
+        double c = 0;
+        int idx = 0; // first crossing, 0 if there is none
+        for (int s = 0; s < n; ++s) {
+            c += prob[(size_t)s * k1 + i] * (trans[(size_t)prev * n + s] ? 1.0 : 0.0);
+            if (c / last > u) {
+                idx = s;
+                break;
+            }
+        }
+        th[i] = (uint8_t)idx;
+        prev = idx;
+    }
+}
+
 int finish(hipStream_t st, bool wait)
 {
     hipError_t e = hipGetLastError();
@@ -191,6 +335,14 @@ int amis_dev_pass_a(const AmisView &v, int64_t Q, int64_t P0, int64_t P, double 
                            cur, logd, logw, partial, dv);
     *rows = old_blocks + new_blocks;
     return finish(st, false);
+}
+
+int amis_dev_draw(int k1, int n, int64_t N, uint64_t seed, uint64_t step, const double *a, const double *prob, const uint8_t *trans,
+                  double *ss, uint8_t *theta8, void *stream)
+{
+    hipLaunchKernelGGL(draw_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, k1, n, N, seed, step, a, prob, trans,
+                       ss, theta8);
+    return finish((hipStream_t)stream, false);
 }
 
 int amis_dev_pass_a_rows(int64_t P0, int64_t P)

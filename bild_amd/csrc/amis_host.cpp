@@ -142,6 +142,7 @@ struct bild_amis {
         uint8_t *theta8 = nullptr; // fused step: the states as they went up for the likelihood (P x k1)
         double *partial = nullptr, *mean = nullptr;
         int64_t partial_cap = 0;
+        double *draw_par = nullptr;     // device-side draws: [a (k1) | slot weights (n x k1) | transitions (n x n bytes)]
         double *partial_host = nullptr; // pinned: the partial sums of a pass on their way down
         int64_t partial_host_cap = 0;
         void *stage = nullptr; // pinned host memory: the new samples of a step on their way up
@@ -257,7 +258,7 @@ int dev_regrow(bild_amis &m, T *&ptr, size_t old_count, size_t new_count)
 void dev_release(bild_amis::Dev &d)
 {
     void *all[] = {d.a, d.dir_norm, d.head, d.pair, d.ss, d.log_ss, d.logL, d.logd, d.cur, d.logw, d.rel, d.has_zero, d.first,
-                   d.pcode, d.theta, d.theta8, d.partial, d.mean};
+                   d.pcode, d.theta, d.theta8, d.partial, d.mean, d.draw_par};
     for (void *q : all)
         if (q) (void)hipFree(q);
     if (d.stage) (void)hipHostFree(d.stage);
@@ -271,7 +272,9 @@ int dev_reserve(bild_amis &m, int64_t P, int64_t Q)
     bild_amis::Dev &d = m.dev;
     const size_t k1 = m.k1, k = m.k, n = m.n;
     int rc;
+    bool regrown = false;
     if (P > d.cap) {
+        regrown = true;
         const int64_t cap = std::max<int64_t>(P, d.cap * 2);
         const size_t have = (size_t)d.P;
         if ((rc = dev_regrow(m, d.ss, have * k1, cap * k1)) || (rc = dev_regrow(m, d.log_ss, have * k1, cap * k1)) ||
@@ -284,6 +287,7 @@ int dev_reserve(bild_amis &m, int64_t P, int64_t Q)
         d.cap = cap;
     }
     if (Q > d.qcap) {
+        regrown = true;
         const int64_t qcap = std::max<int64_t>(Q, d.qcap * 2 + 8);
         const size_t have = (size_t)d.Q;
         if ((rc = dev_regrow(m, d.a, have * k1, qcap * k1)) || (rc = dev_regrow(m, d.dir_norm, have, (size_t)qcap)) ||
@@ -293,7 +297,7 @@ int dev_reserve(bild_amis &m, int64_t P, int64_t Q)
     }
     if (!d.mean) AMIS_HIP(hipMalloc((void **)&d.mean, k1 * sizeof(double)));
     // (the device-to-device copies of a regrowth ran on the null stream; the passes may run on another one)
-    AMIS_HIP(hipDeviceSynchronize());
+    if (regrown) AMIS_HIP(hipDeviceSynchronize());
     return BILD_OK;
 }
 
@@ -627,10 +631,11 @@ int bild_amis_use_device(bild_amis *m, int enable)
 // everything runs on the model's stream, so the only synchronisations are the three copies of partial sums.  The host's
 // copy of the pool catches up when somebody asks for it (host_catch_up).
 static int amis_step_impl(bild_amis *m, int64_t N, const double *ss, const int64_t *thetas, const double *logLs, double *evidence,
-                          const bild_model *model, const bild_trajset *ts, unsigned flags)
+                          const bild_model *model, const bild_trajset *ts, unsigned flags, const uint64_t *rng_seed = nullptr)
 {
     const bool fused = model != nullptr;
-    if (!m || !ss || !thetas || (!fused && !logLs) || !evidence || N < 1) return BILD_ERR_INVALID;
+    const bool draw = fused && rng_seed != nullptr; // the samples are drawn on the device (amis_device.hip: draw_kernel)
+    if (!m || (!draw && (!ss || !thetas)) || (!fused && !logLs) || !evidence || N < 1) return BILD_ERR_INVALID;
     if (fused && (!m->dev.on || !ts)) {
         m->err = "fused step: the pooled samples must be on the device (bild_amis_use_device)";
         return BILD_ERR_INVALID;
@@ -641,12 +646,14 @@ static int amis_step_impl(bild_amis *m, int64_t N, const double *ss, const int64
     const size_t Q = m->a.size(); // proposals used so far, the current one last
     const int64_t P0 = m->total();
     hipStream_t st = nullptr;
-    for (int64_t r = 0; r < N; ++r)
-        for (int i = 0; i < k1; ++i)
-            if (thetas[(size_t)r * k1 + i] < 0 || thetas[(size_t)r * k1 + i] >= n) {
-                m->err = "state index out of range";
-                return BILD_ERR_INVALID;
-            }
+    if (!draw) {
+        uint64_t bad = 0; // (one branch-free pass: the states are checked again where they are narrowed / used)
+        for (size_t i = 0, e = (size_t)N * k1; i < e; ++i) bad |= (uint64_t)((uint64_t)thetas[i] >= (uint64_t)n);
+        if (bad) {
+            m->err = "state index out of range";
+            return BILD_ERR_INVALID;
+        }
+    }
 
     // BILD_AMIS_TRACE=1: where a step spends its time (microseconds), on stderr
     static const bool trace = getenv("BILD_AMIS_TRACE") != nullptr;
@@ -664,7 +671,9 @@ static int amis_step_impl(bild_amis *m, int64_t N, const double *ss, const int64
         int rc;
         if ((rc = dev_push(*m, false))) return rc; // proposals not yet mirrored (and room for them)
         if ((rc = dev_reserve(*m, P, (int64_t)Q))) return rc;
-        const size_t nseg = (size_t)N * k1, need = nseg * sizeof(double) + ((nseg + 15) & ~(size_t)15) + 64;
+        const size_t nseg = (size_t)N * k1;
+        const size_t par_bytes = ((size_t)(k1 + n * k1) * sizeof(double) + (size_t)n * n + 15) & ~(size_t)15;
+        const size_t need = (draw ? par_bytes : nseg * sizeof(double) + ((nseg + 15) & ~(size_t)15)) + 64;
         if (need > d.stage_bytes) {
             if (d.stage) (void)hipHostFree(d.stage);
             d.stage = nullptr;
@@ -675,11 +684,28 @@ static int amis_step_impl(bild_amis *m, int64_t N, const double *ss, const int64
             }
             d.stage_bytes = need * 2;
         }
-        std::memcpy(d.stage, ss, nseg * sizeof(double));
         uint8_t *t8 = (uint8_t *)d.stage + nseg * sizeof(double);
-        int32_t *status = (int32_t *)(t8 + ((nseg + 15) & ~(size_t)15));
+        int32_t *status = draw ? (int32_t *)((char *)d.stage + par_bytes) : (int32_t *)(t8 + ((nseg + 15) & ~(size_t)15));
         status[0] = status[1] = 0;
-        for (size_t i = 0; i < nseg; ++i) t8[i] = (uint8_t)thetas[i]; // (range checked above)
+        if (draw) {
+            // parameters of the current proposal for the draw kernel: concentrations, slot weights as probabilities
+            // (bild_amis_sample_traces: exp(logp - logsumexp over the states of a slot)), allowed transitions
+            double *par = (double *)d.stage;
+            const std::vector<double> &A = m->a.back(), &L = m->logp.back();
+            for (int j = 0; j < k1; ++j) par[j] = A[j];
+            for (int i = 0; i < k1; ++i) {
+                const double norm = lse(n, L.data() + i, k1, [](int) { return true; });
+                for (int s2 = 0; s2 < n; ++s2) par[k1 + (size_t)s2 * k1 + i] = std::exp(L[(size_t)s2 * k1 + i] - norm);
+            }
+            std::memcpy(par + k1 + (size_t)n * k1, m->trans.data(), (size_t)n * n);
+            if (!d.draw_par && hipMalloc((void **)&d.draw_par, par_bytes) != hipSuccess) {
+                m->err = "fused step: out of device memory";
+                return BILD_ERR_NOMEM;
+            }
+        } else {
+            std::memcpy(d.stage, ss, nseg * sizeof(double));
+            for (size_t i = 0; i < nseg; ++i) t8[i] = (uint8_t)thetas[i]; // (range checked above)
+        }
         lap("[amis step fused] stage");
         // everything of this step goes to the model's own stream: the copies, the likelihood, the passes
         void *stream = bild::internal_model_stream(model);
@@ -688,8 +714,16 @@ static int amis_step_impl(bild_amis *m, int64_t N, const double *ss, const int64
             return BILD_ERR_HIP;
         }
         st = (hipStream_t)stream;
-        if (hipMemcpyAsync(d.ss + (size_t)P0 * k1, d.stage, nseg * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
-            hipMemcpyAsync(d.theta8 + (size_t)P0 * k1, t8, nseg, hipMemcpyHostToDevice, st) != hipSuccess) {
+        if (draw) {
+            const double *dp = d.draw_par;
+            if (hipMemcpyAsync(d.draw_par, d.stage, par_bytes, hipMemcpyHostToDevice, st) != hipSuccess ||
+                bild::amis_dev_draw(k1, n, N, *rng_seed, (uint64_t)m->steps, dp, dp + k1, (const uint8_t *)(dp + k1 + (size_t)n * k1),
+                                    d.ss + (size_t)P0 * k1, d.theta8 + (size_t)P0 * k1, (void *)st)) {
+                m->err = "fused step: drawing the samples failed";
+                return BILD_ERR_HIP;
+            }
+        } else if (hipMemcpyAsync(d.ss + (size_t)P0 * k1, d.stage, nseg * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
+                   hipMemcpyAsync(d.theta8 + (size_t)P0 * k1, t8, nseg, hipMemcpyHostToDevice, st) != hipSuccess) {
             m->err = "fused step: upload failed";
             return BILD_ERR_HIP;
         }
@@ -768,7 +802,9 @@ static int amis_step_impl(bild_amis *m, int64_t N, const double *ss, const int64
         if ((rc = dev_partials(mm, (int64_t)rows * 2, part, st))) return rc;
         if (fused) {
             // the stream has been waited for: the likelihood's verdict on the rows is in, and the samples are pooled
-            const int32_t *status = (const int32_t *)((uint8_t *)d.stage + (size_t)N * k1 * sizeof(double) + (((size_t)N * k1 + 15) & ~(size_t)15));
+            const size_t par_bytes2 = ((size_t)(k1 + n * k1) * sizeof(double) + (size_t)n * n + 15) & ~(size_t)15;
+            const int32_t *status = draw ? (const int32_t *)((char *)d.stage + par_bytes2)
+                                         : (const int32_t *)((uint8_t *)d.stage + (size_t)N * k1 * sizeof(double) + (((size_t)N * k1 + 15) & ~(size_t)15));
             if (status[0] != 0) {
                 m->err = "interval lengths of a sample are not non-negative finite numbers (of a point on the simplex)";
                 return BILD_ERR_INVALID;
@@ -1013,6 +1049,25 @@ int bild_amis_step_fused(bild_amis *m, const bild_model *model, const bild_trajs
 {
     if (!model || !ts) return BILD_ERR_INVALID;
     return amis_step_impl(m, N, ss, thetas, nullptr, evidence, model, ts, flags);
+}
+
+int bild_amis_step_device_rng(bild_amis *m, const bild_model *model, const bild_trajset *ts, int64_t N, uint64_t seed, unsigned flags,
+                              double *evidence)
+{
+    if (!model || !ts) return BILD_ERR_INVALID;
+    return amis_step_impl(m, N, nullptr, nullptr, nullptr, evidence, model, ts, flags, &seed);
+}
+
+// the pooled samples themselves (fused steps and device-side draws leave them in HBM until somebody asks):
+// ss (P x k1), thetas (P x k1 int64); either may be NULL
+int bild_amis_pool_samples(const bild_amis *m, double *ss, int64_t *thetas)
+{
+    if (!m) return BILD_ERR_INVALID;
+    if (int rc = host_catch_up(const_cast<bild_amis &>(*m))) return rc;
+    if (ss) std::copy(m->ss.begin(), m->ss.end(), ss);
+    if (thetas)
+        for (size_t i = 0; i < m->theta.size(); ++i) thetas[i] = m->theta[i];
+    return BILD_OK;
 }
 
 // Choice of the next k in the adaptive-k loop (reference bild/choicesampler.py:115-210): for every row of the

@@ -374,6 +374,13 @@ int bild_amis_step(bild_amis *m, int64_t N, const double *ss, const int64_t *the
  * when it is asked for.  Same results as bild_logl_st followed by bild_amis_step. */
 int bild_amis_step_fused(bild_amis *m, const bild_model *model, const bild_trajset *ts, int64_t N,
                          const double *ss, const int64_t *thetas, unsigned flags, double *evidence);
+/* The same with the N samples DRAWN on the device from the current proposal -- a counter-based generator (Philox-4x32-10)
+ * keyed by `seed`, one stream per (step, sample); gamma variates by Marsaglia-Tsang, traces slot by slot from the CFC
+ * weights.  Opt-in: not the reference's NumPy random stream (bild/amis.py:831-832), the same sampler in distribution.
+ * Nothing goes up but the proposal's parameters.  bild_amis_pool_samples brings the pooled samples to the host. */
+int bild_amis_step_device_rng(bild_amis *m, const bild_model *model, const bild_trajset *ts, int64_t N,
+                              uint64_t seed, unsigned flags, double *evidence);
+int bild_amis_pool_samples(const bild_amis *m, double *ss /* P x k1 */, int64_t *thetas /* P x k1 */);
 /* keep the pooled samples in HBM and run the passes of bild_amis_step over them on the GPU (enable != 0), or return
  * to the host implementation (0).  Same arithmetic per sample (csrc/amis_math.h); sums are formed per block in a fixed
  * order, so results are reproducible and agree with the host's to rounding.  For batches of thousands of samples per

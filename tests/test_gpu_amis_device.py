@@ -200,3 +200,78 @@ def test_fused_step_equals_likelihood_call_plus_bookkeeping(built_lib):
     th = bad._core.sample_traces(np.random.random_sample((4, 3000)))
     with pytest.raises(Exception):
         bad._core.step_fused(bad.model.handle(), bad.model.trajset(bad.traj), ss, th)
+
+
+def test_device_rng_is_the_same_sampler_in_distribution(built_lib):
+    """
+    FixedkSampler(rng='device'): the samples of a step are drawn on the GPU (Philox-4x32-10, Marsaglia-Tsang gammas, traces
+    slot by slot).  Not the reference's random numbers, so nothing can be compared sample by sample; the sampler must be the
+    same in distribution: (i) moments of the very first batch (uniform Dirichlet, uniform traces) against their exact
+    values, (ii) the evidence after 6 steps against the NumPy-stream run on the same trajectory, over 20 seeds, within
+    the two runs' own standard errors, (iii) reproducible for a seed, different for another one.
+    """
+    import bild_amd
+    import helpers as H
+    rng = np.random.default_rng(11)
+    model = bild_amd.MultiStateRouse(20, 1, 5, d=3, localization_error=0.1)
+    traj = model.trajectory_from_loopingprofile(H.random_profile(rng, 250, 2, 60), rng=rng)
+    k, N = 3, 4000
+
+    def run(seed, which, steps=6):
+        np.random.seed(seed)
+        s = bild_amd.FixedkSampler(traj, model, k=k, N=N, max_fev=10 ** 9, max_fcomplete=0, rng=which, seed=seed)
+        for _ in range(steps):
+            s.step()
+        return s
+
+    first = run(3, 'device', steps=1)
+    assert first._device_drawn == N and len(first._core) == N
+    ss, thetas = first._pool['ss'], first._pool['thetas']
+    assert ss.shape == (N, k + 1) and thetas.shape == (N, k + 1) and np.all(ss >= 0)
+    assert np.allclose(ss.sum(axis=1), 1.0, rtol=0, atol=1e-12)
+    # Dirichlet(1,1,1,1): mean 1/4, variance 3/80 per coordinate; standard errors of the sample moments at N = 4000
+    assert np.all(np.abs(ss.mean(axis=0) - 0.25) < 5 * np.sqrt(3 / 80 / N))
+    assert np.all(np.abs(ss.var(axis=0) - 3 / 80) < 0.004)
+    assert abs(np.mean(thetas[:, 0]) - 0.5) < 5 * 0.5 / np.sqrt(N)
+    assert np.all(thetas[:, 1:] != thetas[:, :-1])          # two states: every slot switches
+    # the likelihoods the fused step left in the pool are the likelihoods of exactly these samples
+    assert np.array_equal(first._arr['logLs'], model.logL_st_batch(ss, thetas, traj))
+    again, other = run(3, 'device', steps=2), run(4, 'device', steps=2)
+    assert np.array_equal(np.array(again.evidences[:1]), np.array(first.evidences))
+    assert not np.array_equal(np.array(again.evidences), np.array(other.evidences))
+    # (i') a proposal that is not uniform, all regimes of the gamma sampler (a < 1: boosted; a > 1), straight from the core:
+    # every marginal of Dirichlet(a) is Beta(a_j, sum(a) - a_j) -- Kolmogorov-Smirnov against the exact law, 50 000 draws
+    from scipy import stats
+    from bild_amd import _lib
+    a0 = np.array([0.3, 2.5, 7.0, 40.0])
+    logp0 = np.log(np.array([[0.2, 0.5, 0.5, 0.5], [0.8, 0.5, 0.5, 0.5]]))
+    core = _lib.AmisCore(model.transitions, a0, logp0, 1e-2, 1e-3, 0.0)
+    core.use_device(True)
+    core.step_device_rng(model.handle(), model.trajset(traj), 50000, 12345)
+    ss, thetas = core.pool_samples()
+    for j in range(4):
+        pval = stats.kstest(ss[:, j], stats.beta(a0[j], a0.sum() - a0[j]).cdf).pvalue
+        assert pval > 1e-4, (j, pval)
+    assert abs(thetas[:, 0].mean() - 0.8) < 5 * np.sqrt(0.16 / 50000)
+    # (ii) a problem small enough for the exact evidence (every profile evaluated, `fix_exhaustive`).  AMIS evidences after
+    # a few steps scatter by more than their reported errors, low rather than high, under EITHER stream (tools/rng_check.py):
+    # the two streams are held to each other -- same distribution of the evidence over seeds (rank test) --, and both to
+    # the exact value within the scatter.
+    short = model.trajectory_from_loopingprofile(H.random_profile(rng, 80, 2, 25), rng=rng)
+    exact = bild_amd.FixedkSampler(short, model, k=2, N=100, max_fev=10 ** 6, max_fcomplete=10 ** 5)
+    assert exact.exhausted and exact.evidences[-1][1] == 1e-10
+    logev = exact.evidences[-1][0]
+    got = {'device': [], 'numpy': []}
+    for seed in range(12):
+        for which in got:
+            np.random.seed(500 + seed)
+            s_ = bild_amd.FixedkSampler(short, model, k=2, N=4000, max_fev=10 ** 9, max_fcomplete=0, rng=which, seed=500 + seed)
+            for _ in range(8):
+                s_.step()
+            assert (s_._device_drawn > 0) == (which == 'device')
+            got[which].append(s_.evidences[-1][0] - logev)
+    for which, v in got.items():
+        print(f"{which:6s} stream, log-evidence minus the exact {logev:.4f}, 12 seeds:", np.round(v, 3))
+    assert stats.mannwhitneyu(got['device'], got['numpy']).pvalue > 1e-3
+    for which, v in got.items():
+        assert np.max(np.abs(v)) < 3.0, which
