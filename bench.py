@@ -8,29 +8,31 @@ One "step" = one pass of the hot path over one such batch: everything `FixedkSam
 AMIS iteration (reference bild/amis.py:717-739).
 
 What the JSON line reports
-  value / ms_per_step   the batch with candidates and trajectory resident in HBM (`bild_logl_segments_device`,
-                        nothing crosses PCIe inside the timed region) -- the bench contract's definition;
-  api_seam              the SAME batch through the seam the path is defined by: `FixedkSampler.logL(ss, thetas)` with
-                        host arrays in and a host array out per step (native (s, theta) -> segment conversion, one
-                        packed H2D copy out of pinned memory, the launch, one D2H copy, one synchronisation);
-  roofline              the dominant kernel against the fp64 vector peak: `achieved` / `frac` count the operations the
-                        kernel really executes (frames skipped through shared prefixes are not counted);
-                        `canonical_equiv_frac` prices the same time against the reference's dense operation count
-                        (a speed-up figure, may exceed 1, never a utilisation);
-  amis_step             a whole AMIS iteration around the seam (draws, likelihood, refit over all samples drawn so far);
-  large_batch           twenty times the batch on the same trajectory: the throughput regime of the same kernel;
-  cpu_baseline          the reference's own Cython kernel on one host core (and on all cores, secondary).
+  value / ms_per_step   the batch as the sampler produced it -- (s, theta) rows, float64 + one byte per state -- resident
+                        in HBM, a DIFFERENT batch every step (eight of them rotate), through `bild_logl_st_device`: switch
+                        frames (st2profile), cleaning, table walk, frame loop, all inside the timed region; nothing is
+                        converted, ordered or scheduled beforehand and nothing crosses PCIe (the bench contract's definition);
+  api_seam              the same batches through the seam the path is defined by: `FixedkSampler.logL(ss, thetas)` with
+                        host arrays in and a host array out per step (one staged H2D copy, the same kernels, one D2H copy);
+  roofline              the dominant kernel (the frame loop over the work lists) against the fp64 vector peak, from its
+                        average launch duration measured with HIP events on the launch stream; the table-walk kernel beside it;
+  k_sweep, large_batch, config2_one_gpu, config3, config4, single_eval, concentrated_proposal, first_call
+                        the other BASELINE configurations and the regimes a caller meets, each with its own timing;
+  amis_step             whole AMIS iterations around the seam: NumPy random stream (the reference's), and draws on the device;
+  cpu_baseline          the reference's own Cython kernel on one host core.
 
 Multi-GPU: one process per GPU.  `--scaling weak` (default, what the driver runs): every rank evaluates its own 10k
 batch and joins ONE all-gather of the log-likelihoods per step (RCCL), as an AMIS step needs them to form the
 importance weights.  `--scaling strong`: a FIXED workload is partitioned over the ranks -- `--strong-config 1`:
 configs[1] (10k x 1 trajectory, contiguous sample shards), `--strong-config 2`: configs[2] (256 trajectories x 1000
-samples, whole trajectories per rank, `dist.shard_by_trajectory`) -- again one all-gather per step.
+samples, whole trajectories per rank, `dist.shard_by_trajectory`) -- again one all-gather per step.  Every multi-GPU line
+carries `multi_gpu`: per-rank kernel and collective times, the rank count RCCL saw, and the builder's projection.
 
     python bench.py --gpus 1 --steps 50 --warmup 5
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -44,21 +46,37 @@ import numpy as np  # noqa: E402
 
 FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector (= fp64 matrix) peak, AMD spec
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec
+ROTATE = 8                # distinct batches resident in HBM, one per step in turn
 
 
-def build_workload(seed, n_samples, T, k, S=2, N=20, d=3, err=0.1, n_traj=1):
-    """ model, n_traj trajectories, and n_samples candidates per trajectory """
+def kernel_source_hash():
+    """ what the measured HBM traffic (profiles/r03_hbm_traffic.json) belongs to: the kernel sources it was measured on """
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, 'bild_amd', 'csrc')
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith(('.hip', '.h', '.cpp')):
+            with open(os.path.join(csrc, name), 'rb') as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def build_workload(seed, n_samples, T, k, S=2, N=20, d=3, err=0.1, n_traj=1, batches=1):
+    """ model, n_traj trajectories, and `batches` independent batches of n_samples candidates per trajectory """
     import helpers as H
     import bild_amd
     rng_t = np.random.default_rng(1000 + seed)
-    rng_c = np.random.default_rng(2000 + seed)
     model = bild_amd.MultiStateRouse(N, 1., 5., d=d, looppositions=H.LOOPS[S], localization_error=err)
     trajs = []
     for _ in range(n_traj):
         truth = H.random_profile(rng_t, T, S, T // 5)
         trajs.append(model.trajectory_from_loopingprofile(truth, rng=rng_t))
-    ss, thetas = H.candidate_profiles(rng_c, n_samples * n_traj, k, S)
-    return model, trajs, ss, thetas
+    out = []
+    for b in range(batches):
+        rng_c = np.random.default_rng(2000 + seed + 7919 * b)
+        out.append(H.candidate_profiles(rng_c, n_samples * n_traj, k, S))
+    if batches == 1:
+        return model, trajs, out[0][0], out[0][1]
+    return model, trajs, out
 
 
 def _cpu_baseline_loop(model, traj, ss, thetas, T, budget_s, first):
@@ -159,8 +177,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-allcores', action='store_true', help='also time the reference kernel on every host core')
     ap.add_argument('--no-reduce', action='store_true', help='keep all N modes (skip the invariant-subspace reduction)')
-    ap.add_argument('--no-secondary', action='store_true', help='skip the dense / canonical-path side measurements')
-    ap.add_argument('--no-seam', action='store_true', help='skip the api_seam measurement (profiling runs that want the headline launches alone)')
+    ap.add_argument('--no-secondary', action='store_true', help='skip every side measurement (profiling runs that want the headline launches alone)')
+    ap.add_argument('--no-seam', action='store_true', help='skip the api_seam measurement')
+    ap.add_argument('--sweep', action='store_true', help='also the N x d* sweep of SURVEY 8(d) (chain lengths 4 ... 32, one and two localization errors)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help="collective backend; 'gloo' (log-likelihoods staged through host memory) rehearses the "
                          "multi-rank path on a box with fewer GPUs than ranks")
@@ -194,45 +213,48 @@ def main():
         dist.barrier()
 
     import bild_amd
+    import helpers as H
     from bild_amd import _lib
-    from bild_amd.profiles import segments_from_st
     from bild_amd import dist as bdist
 
     T, k = args.T, args.k
     dev = torch.device('cuda', dev_index)
+    stream_of = lambda: torch.cuda.current_stream().cuda_stream  # noqa: E731
 
     # ---- the workload of this rank ------------------------------------------------------------------------
     if args.scaling == 'weak':
         n = args.samples
-        model, trajs, ss, thetas = build_workload(rank, n, T, k, S=args.states)
+        model, trajs, batches = build_workload(rank, n, T, k, S=args.states, batches=ROTATE)
         traj_id = None
         n_global = n * world
         sizes = [n] * world
         workload = (f'configs[1]: {n} profile samples x 1 trajectory per GPU, T={T}, {args.states}-state Rouse N=20 d=3 '
-                    f'd*=1, k={k} switches, fp64')
+                    f'd*=1, k={k} switches, fp64; {ROTATE} distinct batches resident in HBM as (s, theta) rows, one per step in turn')
     elif args.strong_config == 1:
         n_global = args.samples
-        model, trajs, ss, thetas = build_workload(0, n_global, T, k, S=args.states)
+        model, trajs, full = build_workload(0, n_global, T, k, S=args.states, batches=ROTATE)
         lo, hi = bdist.shard_bounds(n_global, world, rank)
-        ss, thetas, traj_id = ss[lo:hi], thetas[lo:hi], None
+        batches = [(ss_[lo:hi], th_[lo:hi]) for ss_, th_ in full]
+        traj_id = None
         n = hi - lo
         sizes = [b - a for a, b in (bdist.shard_bounds(n_global, world, r) for r in range(world))]
         workload = (f'configs[1] strong: {n_global} profile samples x 1 trajectory split over {world} GPU(s), T={T}, '
                     f'{args.states}-state, k={k}, fp64')
     else:
         n_traj_total, per = 256, 1000
-        model, trajs_all, ss_all, thetas_all = build_workload(0, per, T, k, S=args.states, n_traj=n_traj_total)
+        model, trajs_all, full = build_workload(0, per, T, k, S=args.states, n_traj=n_traj_total, batches=2)
         owners = bdist.shard_by_trajectory([T] * n_traj_total, [per] * n_traj_total, world)
         mine = owners[rank]
         trajs = [trajs_all[j] for j in mine]
         rows = np.concatenate([np.arange(j * per, (j + 1) * per) for j in mine])
-        ss, thetas = ss_all[rows], thetas_all[rows]
+        batches = [(ss_[rows], th_[rows]) for ss_, th_ in full]
         traj_id = np.repeat(np.arange(len(mine)), per).astype(np.int32)
         n = len(rows)
         n_global = n_traj_total * per
         sizes = [len(o) * per for o in owners]
         workload = (f'configs[2] strong: {n_traj_total} trajectories x {per} samples sharded by trajectory over {world} '
                     f'GPU(s) ({len(mine)} trajectories on this rank), T={T}, {args.states}-state, k={k}, fp64')
+    ss, thetas = batches[0]
 
     model.path = args.path
     if args.no_reduce:
@@ -240,34 +262,38 @@ def main():
         model._handle = _lib.ModelHandle(a_['B'], a_['G'], a_['Sig'], a_['M0'], a_['C0'], model.measurement, reduce=False)
     h = model.handle()
     ts = model.trajset(trajs if traj_id is not None else trajs[0])      # trajectories resident in HBM
-    seg_start, seg_state = segments_from_st(ss, thetas, T)
-    d_start = torch.from_numpy(seg_start).to(dev)                        # candidates resident in HBM
-    d_state = torch.from_numpy(seg_state).to(dev)
+    d_batches = [(torch.from_numpy(np.ascontiguousarray(ss_)).to(dev), torch.from_numpy(th_.astype(np.uint8)).to(dev))
+                 for ss_, th_ in batches]                                 # candidates resident in HBM, as the sampler produced them
     d_tid = torch.from_numpy(traj_id).to(dev) if traj_id is not None else None
-    # launch order of the resident candidates (a derived descriptor like the segments themselves: computed on the host
-    # from the same (s, theta) batch, resident in HBM before the timed region; the api_seam figure includes computing it)
-    _lib.logl_segments(h, ts, seg_start, seg_state, traj_id, path=args.path)   # one evaluation of the batch: the set's tables exist now
-    order = _lib.schedule_segments(h, ts, seg_start, seg_state, traj_id, path=args.path)
-    d_order = None if np.array_equal(order, np.arange(len(order))) else torch.from_numpy(order).to(dev)   # identity: nothing to pass
+    _lib.logl_st(h, ts, ss, thetas, traj_id, path=args.path)             # one evaluation: the set's tables exist now
     pad = max(sizes)
     d_out = torch.zeros(pad, dtype=torch.float64, device=dev)
     d_all = torch.empty(pad * world, dtype=torch.float64, device=dev)
+    turn = [0]
+    coll_events = []
 
-    def step(path, prefix=True):
-        stream = torch.cuda.current_stream().cuda_stream
-        _lib.logl_segments_device(h, ts, n, k + 1, d_start.data_ptr(), d_state.data_ptr(),
-                                  d_tid.data_ptr() if d_tid is not None else 0, d_out.data_ptr(), stream=stream, path=path,
-                                  d_order=d_order.data_ptr() if (prefix and d_order is not None) else 0, prefix=prefix)
+    def step(path=None, **kw):
+        d_ss, d_th = d_batches[turn[0] % len(d_batches)]
+        turn[0] += 1
+        _lib.logl_st_device(h, ts, n, k + 1, d_ss.data_ptr(), d_th.data_ptr(), d_out.data_ptr(),
+                            d_traj_id=d_tid.data_ptr() if d_tid is not None else 0, stream=stream_of(), path=path or args.path, **kw)
         if world > 1:                                 # the one collective of an AMIS step
             if args.backend == 'nccl':
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
                 bdist.all_gather_logl(d_out, d_all)
+                e1.record()
+                coll_events.append((e0, e1))
             else:
                 d_all.copy_(bdist.all_gather_logl(d_out.cpu()))
 
-    def timed(fn, steps, warmup):
+    def timed(fn, steps, warmup, sample=4, handle=None):
+        # (kernel durations from HIP events around every `sample`-th launch of the timed region: the events cost a few
+        # microseconds per launch, which every step would otherwise pay)
         for _ in range(warmup):
             fn()
-        _lib.kernel_timing(True)
+        coll_events.clear()
+        _lib.kernel_timing(sample if steps >= 2 * sample else 1)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -280,25 +306,34 @@ def main():
         dt = time.perf_counter() - t0
         _lib.kernel_timing(False)
         kms, launches, kname = _lib.kernel_timing_read()
-        timed.frames_per_launch = _lib.frames_run_read(h) / max(launches, 1)   # counted on the device by the tasks themselves
+        wms, wl = _lib.kernel_timing_read_walk()
+        timed.frames_per_launch = _lib.frames_run_read(handle or h) / max(launches, 1)   # counted on the device by the tasks themselves
+        timed.walk_ms = wms / max(wl, 1)
+        timed.local_dt = dt
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == 'nccl' else 'cpu')
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt, kms / max(launches, 1), kname
 
-    dt, kernel_ms, kname = timed(lambda: step(args.path), args.steps, args.warmup)
+    dt, kernel_ms, kname = timed(step, args.steps, args.warmup)
+    walk_ms = timed.walk_ms
     value = n_global * args.steps / dt
     frames_total = float(sum(len(trajs[j]) for j in (traj_id if traj_id is not None else np.zeros(n, dtype=int))))
     frames_frac = timed.frames_per_launch / frames_total
 
     # ---- roofline of the dominant kernel: executed operations against the fp64 vector peak --------------------
-    traffic = None
+    traffic, traffic_note = None, 'no measurement for this workload / these kernel sources'
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r02_hbm_traffic.json')) as f:
+        with open(os.path.join(ROOT, 'profiles', 'r03_hbm_traffic.json')) as f:
             tj = json.load(f)
         if tj['workload'] == {'samples': n, 'T': T, 'k': k, 'path': args.path} and args.states == 2:
-            traffic = tj['traffic_bytes_corrected']
+            if tj.get('kernel_source_hash') == kernel_source_hash():
+                traffic = tj['traffic_bytes_corrected']
+                traffic_note = 'HBM bytes per step (both kernels), rocprofv3 PMC passes, gfx950 correction applied (profiles/r03_hbm_traffic.json)'
+            else:
+                traffic_note = ('profiles/r03_hbm_traffic.json was measured on other kernel sources (hash %s, now %s): not quoted'
+                                % (tj.get('kernel_source_hash'), kernel_source_hash()))
     except Exception:
         pass
     can, exe = _lib.flop_count(h, ts, n, traj_id=traj_id, path=args.path)
@@ -306,35 +341,45 @@ def main():
     prefix_bytes, prefix_ms = _lib.prefix_info(ts)
     ksec = kernel_ms * 1e-3
     is_mfma = 'mfma' in kname
-    alg_bytes = n * (k + 1) * 8 + n * 8 + sum(len(t) for t in trajs) * 3 * 8
+    alg_bytes = n * (k + 1) * 9 + n * 8 + sum(len(t) for t in trajs) * 3 * 8
+    table_bytes = n * k * 64          # per switch: a 16-byte entry, two running sums, at most one pair entry with two more
     roofline = {
         'bound': 'mfma' if is_mfma else 'valu',
         'pipe': ('fp64 matrix pipe (v_mfma_f64_4x4x4_4b)' if is_mfma else
                  'fp64 vector FMA issue (v_fma_f64 / v_fmac_f64_dpp); no MFMA in this kernel'),
-        'kernel': kname,
+        'kernel': kname + ' over the work lists (the frame loop: chains of three and more close switches)',
         'achieved': exe / ksec / 1e12, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
         'frac': exe / ksec / 1e12 / FP64_PEAK_TFLOPS,
         'flops_basis': 'operations the kernel executes: modal recursion on the reduced chain, frames actually run',
         'flop_per_eval_executed': exe / n,
         'frames_executed_fraction': frames_frac,
         'frames_note': 'share of the (candidate, frame) pairs the launch ran itself, counted on the device; the rest comes out '
-                       'of the prefix table: a candidate starts at its first switch and, once its filter state agrees with '
-                       'the switch-free one behind a switch, takes the table\'s sums up to its next switch',
-        'prefix_table': {'bytes': prefix_bytes, 'build_ms_once_per_trajectory_set': prefix_ms,
-                         'note': 'switch-free filter states per (trajectory, state, frame): built once per trajectory set by '
-                                 'the likelihood kernel itself, outside the timed region like the upload of the trajectory'},
+                       'of tables: the table-walk kernel (one lane per candidate) finishes every candidate whose switches are '
+                       'covered by the transient / pair tables and hands the others to the frame loop, where a chain of close '
+                       'switches starts at its second switch from the transient state table and ends at the first frame at which '
+                       'its filter state agrees with the switch-free one',
         'kernel_ms': kernel_ms,
+        'walk_kernel': {'kernel': 'walk_kernel (csrc/walk.hip): (s, theta) -> switch frames, cleaning, table walk; one lane per candidate',
+                        'kernel_ms': walk_ms,
+                        'hbm_algorithmic_GBps': (alg_bytes + table_bytes) / max(walk_ms * 1e-3, 1e-12) / 1e9,
+                        'hbm_frac': (alg_bytes + table_bytes) / max(walk_ms * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS},
+        'latency_note': 'neither roof binds: the step is the walk kernel (one memory round trip per group of switches) plus the '
+                        'longest chain of close switches, run frame by frame by ONE wavefront (DESIGN.md section 4)',
+        'tables': {'bytes': prefix_bytes, 'build_ms_device': prefix_ms,
+                   'note': 'prefix / transient / transient-state / pair tables of the trajectory set, built once by the likelihood '
+                           'kernel itself at the first evaluation (device time of the builds; `first_call` below has the wall time)'},
         'traffic': traffic,
-        'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC passes, gfx950 correction applied; profiles/r02_hbm_traffic.json)',
-        'algorithmic_bytes_per_launch': alg_bytes,
-        'hbm_algorithmic_GBps': alg_bytes / ksec / 1e9,
-        'hbm_frac': alg_bytes / ksec / 1e9 / HBM_PEAK_GBS,
+        'traffic_note': traffic_note,
+        'algorithmic_bytes_per_launch': alg_bytes + table_bytes,
+        'algorithmic_bytes_note': '(s, theta) rows 9 B per segment, results 8 B, trajectory 24 KB, + 64 B of table entries per switch',
+        'hbm_algorithmic_GBps': (alg_bytes + table_bytes) / ((kernel_ms + walk_ms) * 1e-3) / 1e9,
+        'hbm_frac': (alg_bytes + table_bytes) / ((kernel_ms + walk_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
         'attainable_fma_peak': 51.5,
         'attainable_note': 'register-resident v_fma_f64 loop measured on MI355X: 51.5 TFLOP/s at >= 2 waves/SIMD (profiles/r01_f64_rates.txt)',
         'flop_per_eval_canonical': can / n,
-        'canonical_equiv_frac': can / ksec / 1e12 / FP64_PEAK_TFLOPS,
-        'canonical_note': ('SURVEY 8a canonical F (dense recursion on all N monomers) / kernel time / peak: a SPEED-UP '
-                           'equivalent (the kernel runs %d of %d modes in the eigenbasis of B), not a utilisation'
+        'canonical_equiv_frac': can / ((kernel_ms + walk_ms) * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+        'canonical_note': ('SURVEY 8a canonical F (dense recursion on all N monomers) / device time of a step / peak: a SPEED-UP '
+                           'equivalent (the kernels run %d of %d modes in the eigenbasis of B and 0.3 %% of the frames), not a utilisation'
                            % (h.query(_lib.Q_NEFF), h.query(_lib.Q_N))),
     }
 
@@ -345,9 +390,33 @@ def main():
         'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'config': {'workload': workload, 'samples_this_rank': n, 'samples_global': n_global, 'T': T, 'k': k,
                    'states': args.states, 'path': args.path,
+                   'entry': 'bild_logl_st_device: (s, theta) rows resident in HBM -> log-likelihoods in HBM',
                    'collective': ('all_gather(float64[%d]) per step, %s' % (pad, args.backend)) if world > 1 else 'none (1 GPU)'},
         'roofline': roofline,
     }
+
+    if world > 1:
+        # ---- what a scaling run needs to explain itself -----------------------------------------------------------------
+        coll_ms = float(np.mean([a.elapsed_time(b) for a, b in coll_events])) if coll_events else None
+        info = torch.tensor([kernel_ms + walk_ms, coll_ms if coll_ms is not None else -1.0, timed.local_dt / args.steps * 1e3],
+                            dtype=torch.float64, device=dev if args.backend == 'nccl' else 'cpu')
+        gathered = [torch.zeros_like(info) for _ in range(world)]
+        dist.all_gather(gathered, info)
+        per_rank = [[float(v) for v in g.tolist()] for g in gathered]
+        result['multi_gpu'] = {
+            'ranks_seen': dist.get_world_size(), 'backend': args.backend,
+            'per_rank_kernel_ms': [p[0] for p in per_rank],
+            'per_rank_collective_ms': [p[1] if p[1] >= 0 else None for p in per_rank],
+            'per_rank_ms_per_step': [p[2] for p in per_rank],
+            'collective': 'torch.distributed all_gather_into_tensor of float64[%d] per rank on the kernels\' stream (RCCL over xGMI); '
+                          'events around the call' % pad,
+            'projection': 'profiles/r03_scaling_projection.txt: weak scaling = the one-GPU step + the collective; the step is '
+                          'latency-bound (longest chain), so the aggregate grows with the rank count until the collective '
+                          '(20-40 us on 8 GPUs, latency-bound at 80 KB per rank) is a third of it',
+        }
+
+    if rank == 0 and world == 1:
+        result['parity_note'] = 'every timed batch is checked below against the reference Cython kernel (parity_max_abs_diff_vs_cpu_baseline)'
 
     # ---- the seam: FixedkSampler.logL(ss, thetas), host arrays in, host array out ----------------------------
     if traj_id is None and not args.no_seam:
@@ -355,100 +424,297 @@ def main():
         sampler = bild_amd.FixedkSampler(trajs[0], model_for_sampler, k=k, N=len(ss), max_fcomplete=0)
         if world > 1 and args.scaling == 'strong':
             # replicated AMIS loop: every rank passes the FULL batch, evaluates its shard, one all-gather
-            _, _, ss_full, thetas_full = build_workload(0, n_global, T, k, S=args.states)
-            seam_args = (ss_full, thetas_full)
+            seam_batches = [build_workload(0, n_global, T, k, S=args.states)[2:4]]
         else:
-            seam_args = (ss, thetas)
-        got = sampler.logL(*seam_args)
-        sdt, skms, _ = timed(lambda: sampler.logL(*seam_args), args.steps, min(args.warmup, 3))
+            seam_batches = batches
+        sturn = [0]
+
+        def seam_step():
+            ss_, th_ = seam_batches[sturn[0] % len(seam_batches)]
+            sturn[0] += 1
+            return sampler.logL(ss_, th_)
+        got = sampler.logL(*seam_batches[0])
+        sdt, skms, _ = timed(seam_step, args.steps, min(args.warmup, 3))
         result['api_seam'] = {
             'what': 'FixedkSampler.logL(ss, thetas): host (N,k+1) float64 + int64 in, host (N,) float64 out, per step '
-                    '(bild/amis.py:717-739)',
+                    '(bild/amis.py:717-739); the rows go up as they are (float64 + one byte per state) and are converted on the device',
             'value': (n_global if args.scaling == 'strong' else n * world) * args.steps / sdt, 'unit': 'evals/s',
-            'ms_per_call': sdt / args.steps * 1e3, 'kernel_ms': skms,
+            'ms_per_call': sdt / args.steps * 1e3, 'kernel_ms': skms, 'walk_kernel_ms': timed.walk_ms,
         }
-        step(args.path)
-        torch.cuda.synchronize()
         if not (world > 1 and args.scaling == 'strong'):
+            turn[0] = 0
+            step()
+            torch.cuda.synchronize()
             result['api_seam']['max_abs_diff_vs_device_entry'] = float(np.max(np.abs(got - d_out[:n].cpu().numpy())))
 
-    if rank == 0 and world == 1 and args.scaling == 'weak' and not args.no_secondary and n == 10000:
-        # the throughput regime of the same kernel: twenty times the batch on the same trajectory (the 10k headline is bound
-        # by the latency of its longest chain of close switches)
-        import helpers as H
+    secondary = rank == 0 and world == 1 and args.scaling == 'weak' and not args.no_secondary
+
+    def resident(ss_, th_, tid_=None):
+        return (torch.from_numpy(np.ascontiguousarray(ss_)).to(dev), torch.from_numpy(th_.astype(np.uint8)).to(dev),
+                torch.from_numpy(tid_).to(dev) if tid_ is not None else None)
+
+    def time_resident(handle, tset, d_ss, d_th, d_tid_, count, k1, reps, warm=2, **kw):
+        out_ = torch.empty(count, dtype=torch.float64, device=dev)
+
+        def go():
+            _lib.logl_st_device(handle, tset, count, k1, d_ss.data_ptr(), d_th.data_ptr(), out_.data_ptr(),
+                                d_traj_id=d_tid_.data_ptr() if d_tid_ is not None else 0, stream=stream_of(), **kw)
+        dt_, kms_, _ = timed(go, reps, warm, handle=handle)
+        return dt_ / reps, kms_, timed.walk_ms, timed.frames_per_launch, out_
+
+    if secondary:
+        # ---- how the step moves with the number of switches per candidate ---------------------------------------------
+        sweep = {}
+        for kk in (2, 4, 8, 15):
+            rng_k = np.random.default_rng(3000 + kk)
+            ss_k, th_k = H.candidate_profiles(rng_k, n, kk, args.states)
+            d1, d2, _ = resident(ss_k, th_k)
+            per, kms_, wms_, fr_, _ = time_resident(h, ts, d1, d2, None, n, kk + 1, 30)
+            sweep[f'k={kk}'] = {'evals_per_s': n / per, 'ms_per_step': per * 1e3, 'frame_loop_kernel_ms': kms_, 'walk_kernel_ms': wms_,
+                                'frames_run_per_candidate': fr_ / n}
+        result['k_sweep'] = {'what': f'{n} candidates with k uniformly placed switches each (Dirichlet(1) interval lengths), resident in '
+                                     'HBM; k = 4 is the headline', **sweep}
+
+        # ---- the throughput regime of the same kernels: twenty times the batch on the same trajectory ------------------
         n_big = 200000
         rng_b = np.random.default_rng(4242)
-        ss_b, thetas_b = H.candidate_profiles(rng_b, n_big, k, args.states)
-        a_b, b_b = segments_from_st(ss_b, thetas_b, T)
-        da_b, db_b = torch.from_numpy(a_b).to(dev), torch.from_numpy(b_b).to(dev)
-        out_b = torch.empty(n_big, dtype=torch.float64, device=dev)
-        order_b = torch.from_numpy(_lib.schedule_segments(h, ts, a_b, b_b, None, path=args.path)).to(dev)
-
-        def big_step():
-            _lib.logl_segments_device(h, ts, n_big, k + 1, da_b.data_ptr(), db_b.data_ptr(), 0, out_b.data_ptr(),
-                                      stream=torch.cuda.current_stream().cuda_stream, path=args.path, d_order=order_b.data_ptr())
-        bdt, bkms, _ = timed(big_step, 10, 2)
+        ss_b, th_b = H.candidate_profiles(rng_b, n_big, k, args.states)
+        d1, d2, _ = resident(ss_b, th_b)
+        per, kms_, wms_, fr_, _ = time_resident(h, ts, d1, d2, None, n_big, k + 1, 10)
         result['large_batch'] = {
-            'what': f'{n_big} candidates on the same trajectory, resident in HBM, launch order of bild_schedule_segments',
-            'value': n_big * 10 / bdt, 'unit': 'evals/s', 'kernel_ms': bkms, 'frames_executed_fraction': timed.frames_per_launch / (n_big * T),
-        }
-        del da_b, db_b, out_b, order_b
+            'what': f'{n_big} candidates on the same trajectory, (s, theta) rows resident in HBM',
+            'value': n_big / per, 'unit': 'evals/s', 'ms_per_step': per * 1e3, 'frame_loop_kernel_ms': kms_, 'walk_kernel_ms': wms_,
+            'frames_executed_fraction': fr_ / (n_big * T)}
+        del d1, d2
 
-    if rank == 0 and world == 1 and args.scaling == 'weak' and not args.no_secondary and not args.no_seam:
-        # a whole AMIS iteration around the seam (bild/amis.py:805-906): draw N samples from the current
-        # proposal (NumPy, the reference's random stream), evaluate them, refit the proposal over ALL samples drawn so far
-        np.random.seed(7)
-        amis_sampler = bild_amd.FixedkSampler(trajs[0], model, k=k, N=n, max_fev=10 ** 9, max_fcomplete=0)
-        t_like = [0.0]
-        inner = amis_sampler.logL
+        # ---- late AMIS: candidates drawn from a proposal that has concentrated on the true switches -------------------
+        truth = np.asarray(trajs[0].meta['loopingprofile'])
+        sw = np.nonzero(np.diff(truth))[0] + 1
+        kc = int(min(len(sw), 8))
+        if kc >= 1:
+            pick = np.sort(np.random.default_rng(5).choice(sw, size=kc, replace=False))
+            mean = np.diff(np.concatenate([[0], pick, [T]])) / T
+            rng_c = np.random.default_rng(6)
+            ss_c = rng_c.dirichlet(mean * 2000.0, size=n)               # switches within a few frames of the true ones
+            th_c = np.empty((n, kc + 1), dtype=np.int64)
+            th_c[:, 0] = truth[0]
+            for i in range(1, kc + 1):
+                th_c[:, i] = truth[min(pick[i - 1], T - 1)]
+            d1, d2, _ = resident(ss_c, th_c)
+            per, kms_, wms_, fr_, _ = time_resident(h, ts, d1, d2, None, n, kc + 1, 30)
+            result['concentrated_proposal'] = {
+                'what': f'{n} candidates with k = {kc} switches drawn from Dirichlet(2000 x true interval lengths): the late-AMIS regime, '
+                        'where the candidates agree on the switches to within a few frames',
+                'evals_per_s': n / per, 'ms_per_step': per * 1e3, 'frame_loop_kernel_ms': kms_, 'walk_kernel_ms': wms_,
+                'frames_run_per_candidate': fr_ / n}
 
-        def timed_logl(ss_, thetas_):
-            t0_ = time.perf_counter()
-            out_ = inner(ss_, thetas_)
-            t_like[0] += time.perf_counter() - t0_
-            return out_
-        amis_sampler.logL = timed_logl
+        # ---- what the reference's own plug points get: one evaluation per call -----------------------------------------
+        prof = H.random_profile(np.random.default_rng(8), T, args.states, T // 5)
         for _ in range(3):
-            amis_sampler.step()
-        t_like[0] = 0.0
-        amis_steps = 8
+            model.logL(prof, trajs[0])
         t0 = time.perf_counter()
-        for _ in range(amis_steps):
-            amis_sampler.step()
-        adt = time.perf_counter() - t0
+        for _ in range(200):
+            model.logL(prof, trajs[0])
+        single = (time.perf_counter() - t0) / 200
+        lat = {}
+        for cnt in (9, 41):
+            profs = np.stack([H.random_profile(np.random.default_rng(100 + i), T, args.states, T // 5) for i in range(cnt)])
+            for _ in range(3):
+                model.logL_batch(profs, trajs[0])
+            t0 = time.perf_counter()
+            for _ in range(100):
+                model.logL_batch(profs, trajs[0])
+            per_call = (time.perf_counter() - t0) / 100
+            lat[f'{cnt}_profiles'] = {'ms_per_call': per_call * 1e3, 'evals_per_s': cnt / per_call}
+        result['single_eval'] = {
+            'what': 'model.logL(profile, traj): ONE expanded profile per call, host to host -- what an unchanged reference gets through '
+                    'the symbol swap of bild/cython_imports.py:3-7 (and the per-sample hook amis.py:734-736); 9 / 41 profiles per call: '
+                    'the batches of postproc.logLR_boundaries (bild/postproc.py:36-59, 2k+1 profiles)',
+            'ms_per_call': single * 1e3, 'evals_per_s': 1.0 / single, **lat}
+
+        # ---- the first evaluation on a fresh trajectory set (all code objects loaded by now): what the tables cost -------
+        rng_f = np.random.default_rng(77)
+        tr2 = model.trajectory_from_loopingprofile(H.random_profile(rng_f, T, args.states, T // 5), rng=rng_f)
+        t0 = time.perf_counter()
+        ts2 = model.trajset(tr2)
+        t1 = time.perf_counter()
+        _lib.logl_st(h, ts2, ss[:100], thetas[:100], path=args.path)
+        t2 = time.perf_counter()
+        _lib.logl_st(h, ts2, ss[:100], thetas[:100], path=args.path)
+        t3 = time.perf_counter()
+        b2, ms2 = _lib.prefix_info(ts2)
+        result['first_call'] = {
+            'what': 'a second trajectory of the same length in the same process: upload, first evaluation of 100 candidates (builds the '
+                    'prefix / transient / state / pair tables), second evaluation of the same 100',
+            'upload_ms': (t1 - t0) * 1e3, 'first_evaluation_ms': (t2 - t1) * 1e3, 'second_evaluation_ms': (t3 - t2) * 1e3,
+            'tables_bytes': b2, 'tables_build_ms_device': ms2}
+
+    if secondary and not args.no_seam:
+        # ---- whole AMIS iterations around the seam (bild/amis.py:805-906) ----------------------------
+        amis = {}
+        for mode, kw in (('numpy_stream', {}), ('device_rng', {'rng': 'device', 'seed': 7})):
+            np.random.seed(7)
+            smp = bild_amd.FixedkSampler(trajs[0], model, k=k, N=n, max_fev=10 ** 9, max_fcomplete=0, **kw)
+            for _ in range(3):
+                smp.step()
+            amis_steps = 10
+            t0 = time.perf_counter()
+            for _ in range(amis_steps):
+                smp.step()
+            adt = time.perf_counter() - t0
+            amis[mode] = {'ms_per_step': adt / amis_steps * 1e3, 'samples_per_s': n * amis_steps / adt,
+                          'fused': bool(smp._fusable()), 'pool_at_the_end': len(smp._core),
+                          'evidence': [float(v) for v in smp.evidences[-1]]}
         result['amis_step'] = {
-            'what': f'FixedkSampler.step() at N = {n}: draws + likelihood + weights / refit / evidence over the pool '
-                    f'({(3 + amis_steps) * n} samples at the end)',
-            'ms_per_step': adt / amis_steps * 1e3, 'likelihood_ms_per_step': t_like[0] / amis_steps * 1e3,
-            'bookkeeping': 'device (csrc/amis_device.hip)' if getattr(amis_sampler._core, 'on_device', False) else 'host (csrc/amis_host.cpp)',
-            'value': n * amis_steps / adt, 'unit': 'samples/s through whole AMIS iterations',
-        }
+            'what': f'FixedkSampler.step() at N = {n}: draws + likelihood + weights / refit / evidence over the pool, one native call per '
+                    'step (bild_amis_step_fused: the samples go up once, likelihood and the three passes over the pool on one stream). '
+                    'numpy_stream: the reference\'s random stream (NumPy draws on the host, 1.0 ms of the step); device_rng: opt-in, '
+                    'the draws on the GPU (Philox-4x32-10, not the reference\'s random numbers)',
+            **amis}
+
+    if secondary:
+        # ---- BASELINE configs[2] on one GPU: 256 trajectories x 1000 candidates ----------------------------------------
+        try:
+            n_traj2, per2 = 256, 1000
+            model2, trajs2, _, _ = build_workload(0, 1, T, k, S=args.states, n_traj=n_traj2)
+            rng2 = np.random.default_rng(99)
+            ss2, th2 = H.candidate_profiles(rng2, n_traj2 * per2, k, args.states)
+            tid2 = np.repeat(np.arange(n_traj2), per2).astype(np.int32)
+            t0 = time.perf_counter()
+            ts_2 = model2.trajset(trajs2)
+            _lib.logl_st(model2.handle(), ts_2, ss2[:1000], th2[:1000], tid2[:1000])
+            build_s = time.perf_counter() - t0
+            d1, d2, d3 = resident(ss2, th2, tid2)
+            per, kms_, wms_, fr_, _ = time_resident(model2.handle(), ts_2, d1, d2, d3, n_traj2 * per2, k + 1, 10)
+            b2, ms2 = _lib.prefix_info(ts_2)
+            result['config2_one_gpu'] = {
+                'what': f'BASELINE configs[2] on ONE GPU: {n_traj2} trajectories x {per2} candidates, T={T}, k={k}, (s, theta) rows and '
+                        'traj_id resident in HBM',
+                'value': n_traj2 * per2 / per, 'unit': 'evals/s', 'ms_per_step': per * 1e3, 'frame_loop_kernel_ms': kms_,
+                'walk_kernel_ms': wms_, 'frames_executed_fraction': fr_ / (n_traj2 * per2 * T),
+                'tables_bytes': b2, 'tables_build_ms_device': ms2, 'upload_and_first_evaluation_s': build_s}
+            del d1, d2, d3, ts_2, model2
+        except Exception as exc:   # (a side measurement must not take the headline down with it)
+            result['config2_one_gpu'] = {'error': repr(exc)}
+
+        # ---- BASELINE configs[3]: 3-state, T = 2000, 5000 candidates per trajectory, mixed missing-frame masks ----------
+        try:
+            rng3 = np.random.default_rng(33)
+            model3 = bild_amd.MultiStateRouse(20, 1., 5., d=3, looppositions=H.LOOPS[3], localization_error=0.1)
+            T3, per3, kinds = 2000, 5000, ['none', 'iid', 'bursty', 'none', 'iid', 'bursty']
+            trajs3 = []
+            for j, kind in enumerate(kinds):
+                miss = H.missing_mask(rng3, T3, kind)
+                if j % 2 == 1:
+                    miss = np.union1d(miss, [0])                      # frame 0 missing in half of them
+                trajs3.append(model3.trajectory_from_loopingprofile(H.random_profile(rng3, T3, 3, T3 // 5), missing_frames=miss, rng=rng3))
+            tid3 = np.repeat(np.arange(len(kinds)), per3).astype(np.int32)
+            ts3 = model3.trajset(trajs3)
+            c3 = {}
+            for kk in (4, 8):
+                ss3, th3 = H.candidate_profiles(rng3, len(kinds) * per3, kk, 3)
+                _lib.logl_st(model3.handle(), ts3, ss3[:500], th3[:500], tid3[:500])
+                d1, d2, d3 = resident(ss3, th3, tid3)
+                per, kms_, wms_, fr_, out3 = time_resident(model3.handle(), ts3, d1, d2, d3, len(tid3), kk + 1, 10)
+                pick = rng3.choice(len(tid3), 6, replace=False)
+                from oracle import oracle
+                worst = 0.0
+                for r_ in pick:
+                    st_ = H.expand(ss3[r_:r_ + 1], th3[r_:r_ + 1], T3)
+                    want = oracle.logl_batch(model3.arrays(), model3.measurement, model3.localization_error, trajs3[tid3[r_]][:], st_)[0]
+                    worst = max(worst, abs(float(out3[r_].item()) - want))
+                c3[f'k={kk}'] = {'evals_per_s': len(tid3) / per, 'ms_per_step': per * 1e3, 'frame_loop_kernel_ms': kms_, 'walk_kernel_ms': wms_,
+                                 'frames_executed_fraction': fr_ / (len(tid3) * T3), 'max_abs_diff_vs_oracle_6_candidates': worst}
+            result['config3'] = {'what': f'BASELINE configs[3]: 3-state Rouse, T={T3}, {per3} candidates per trajectory on {len(kinds)} trajectories '
+                                         '(no missing frames / 10 % i.i.d. / bursty gaps covering 30 %, frame 0 missing in half), resident in HBM', **c3}
+            del ts3, model3
+        except Exception as exc:
+            result['config3'] = {'error': repr(exc)}
+
+        # ---- BASELINE configs[4]: the full adaptive-k inference on 64 trajectories of experimental length ---------------
+        try:
+            rng4 = np.random.default_rng(5)
+            model4 = bild_amd.MultiStateRouse(20, 1, 5, d=3, localization_error=0.1)
+            trajs4 = [model4.trajectory_from_loopingprofile(H.random_profile(rng4, int(rng4.integers(150, 601)), 2, 120), rng=rng4)
+                      for _ in range(64)]
+            model4.logL_segments(np.zeros((1, 1), np.int32), np.zeros((1, 1), np.int32), trajs4, np.zeros(1, np.int32))   # upload
+            np.random.seed(11)
+            _lib.kernel_timing(True)
+            t0 = time.perf_counter()
+            res4 = bild_amd.sample_many(trajs4, model4, return_exceptions=True)
+            wall4 = time.perf_counter() - t0
+            _lib.kernel_timing(False)
+            kms4, launches4, _ = _lib.kernel_timing_read()
+            wms4, wl4 = _lib.kernel_timing_read_walk()
+            ok4 = [r for r in res4 if not isinstance(r, Exception)]
+            evals4 = sum(len(smp['logLs']) for r in ok4 for s_ in r.samplers for smp in s_.samples)
+            result['config4'] = {
+                'what': 'BASELINE configs[4]: bild.core.sample with default settings (adaptive k, N = 100 per AMIS step) on 64 synthetic '
+                        'trajectories of T ~ U{150..600}, fused across trajectories by sample_many; one GPU',
+                'wall_s': wall4, 'trajectories_done': len(ok4), 'likelihood_evaluations': evals4, 'evals_per_s': evals4 / wall4,
+                'gpu_busy_ms': kms4 + wms4, 'gpu_busy_share': (kms4 + wms4) * 1e-3 / wall4, 'kernel_launches': launches4 + wl4,
+                'best_k_histogram': np.bincount([int(r.best_k()) for r in ok4]).tolist()}
+            del model4
+        except Exception as exc:
+            result['config4'] = {'error': repr(exc)}
+
+    if secondary and args.sweep:
+        # ---- chain lengths x number of distinct localization errors, at HEAD ---------------------------------
+        rows = {}
+        for Nm in (4, 8, 16, 20, 32):
+            for errs, name in ((0.1, 'd*=1'), ([0.1, 0.1, 0.25], 'd*=2')):
+                rng_s = np.random.default_rng(Nm)
+                mod = bild_amd.MultiStateRouse(Nm, 1., 5., d=3, localization_error=errs)
+                tr = mod.trajectory_from_loopingprofile(H.random_profile(rng_s, T, 2, T // 5), rng=rng_s)
+                ss_s, th_s = H.candidate_profiles(rng_s, n, k, 2)
+                hs, tss = mod.handle(), mod.trajset(tr)
+                _lib.logl_st(hs, tss, ss_s[:200], th_s[:200])
+                d1, d2, _ = resident(ss_s, th_s)
+                per, kms_, wms_, fr_, _ = time_resident(hs, tss, d1, d2, None, n, k + 1, 20)
+                can_s, _ = _lib.flop_count(hs, tss, n)
+                rows[f'N={Nm} {name}'] = {'evals_per_s': n / per, 'ms_per_step': per * 1e3, 'frame_loop_kernel_ms': kms_, 'walk_kernel_ms': wms_,
+                                          'canonical_equiv_frac': can_s / per / 1e12 / FP64_PEAK_TFLOPS, 'modes': hs.query(_lib.Q_NEFF)}
+        result['sweep'] = {'what': f'{n} candidates x T={T}, k={k}: chain length N and distinct localization errors (SURVEY 8d)', **rows}
 
     if rank == 0 and world == 1 and args.scaling == 'weak':
+        def seg_step(path, **kw):
+            # the segment entry on host-converted lists of batch 0 (frame-by-frame / dense / canonical comparisons)
+            _lib.logl_segments_device(seg_h[0], seg_h[1], n, k + 1, seg_d[0].data_ptr(), seg_d[1].data_ptr(), 0, d_out.data_ptr(),
+                                      stream=stream_of(), path=path, **kw)
+        from bild_amd.profiles import segments_from_st
+        a0, b0 = segments_from_st(ss, thetas, T)
+        seg_d = (torch.from_numpy(a0).to(dev), torch.from_numpy(b0).to(dev))
+        seg_h = [h, ts]
+
+        def default_results():
+            turn[0] = 0
+            step()
+            torch.cuda.synchronize()
+            return d_out[:n].cpu().numpy().copy()
         if not args.no_secondary and prefix_bytes:
             reps = max(5, args.steps // 3)
-            ndt, nkms, nname = timed(lambda: step(args.path, prefix=False), reps, 1)
+            ndt, nkms, nname = timed(lambda: seg_step(args.path, prefix=False), reps, 1)
             _, nexe = _lib.flop_count(h, ts, n, traj_id=traj_id, path=args.path)
-            result['without_prefix_table'] = {
-                'what': 'the same batch with every candidate run frame by frame from frame 0 (BILD_NO_PREFIX, array order)',
+            a_out = d_out[:n].cpu().numpy().copy()
+            result['without_tables'] = {
+                'what': 'batch 0 with every candidate run frame by frame from frame 0 (BILD_NO_PREFIX, array order): the frame loop of '
+                        'the same kernel code in its issue-bound regime',
                 'value': n * reps / ndt, 'unit': 'evals/s', 'kernel': nname, 'kernel_ms': nkms,
                 'achieved': nexe / (nkms * 1e-3) / 1e12, 'frac': nexe / (nkms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
-            }
-            # the same kernel code in its issue-bound regime, beside the default launch's figure
+                'max_abs_diff_vs_default': float(np.max(np.abs(a_out - default_results())))}
             roofline['same_kernel_frame_by_frame'] = {'kernel_ms': nkms, 'achieved': nexe / (nkms * 1e-3) / 1e12,
                                                       'frac': nexe / (nkms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
-                                                      'note': 'every frame of every candidate run (no prefix table): what the frame '
-                                                              'loop itself reaches of the fp64 peak; the default launch runs the '
-                                                              'share of the frames given in frames_executed_fraction (the rest comes '
-                                                              'out of tables) and lasts as long as its longest chain of close '
-                                                              'switches, run by one wavefront (DESIGN.md section 4)'}
-            a_out = d_out[:n].cpu().numpy().copy()
-            step(args.path)
-            torch.cuda.synchronize()
-            result['without_prefix_table']['max_abs_diff_vs_default'] = float(np.max(np.abs(a_out - d_out[:n].cpu().numpy())))
+                                                      'note': 'every frame of every candidate run (no tables): what the frame loop itself '
+                                                              'reaches of the fp64 peak'}
+            sdt_, skms_, _ = timed(lambda: seg_step(args.path, split=False, states=False), reps, 1)
+            result['single_launch'] = {
+                'what': 'batch 0 as ONE launch of the frame-loop kernel (BILD_NO_SPLIT | BILD_NO_STATES: round 2\'s default) on '
+                        'host-converted segment lists resident in HBM',
+                'value': n * reps / sdt_, 'unit': 'evals/s', 'kernel_ms': skms_,
+                'max_abs_diff_vs_default': float(np.max(np.abs(d_out[:n].cpu().numpy() - default_results())))}
         if not args.no_secondary and args.path != 'dense':
             reps = max(3, args.steps // 10)
-            ddt, dkms, dname = timed(lambda: step('dense'), reps, 1)
+            ddt, dkms, dname = timed(lambda: seg_step('dense'), reps, 1)
             dcan, dexe = _lib.flop_count(h, ts, n, path='dense')
             result['dense_path'] = {
                 'what': 'BILD_PATH_DENSE on the reduced chain (C <- B C B + Sig every frame)',
@@ -462,28 +728,21 @@ def main():
             a_ = model.arrays()
             h_full = _lib.ModelHandle(a_['B'], a_['G'], a_['Sig'], a_['M0'], a_['C0'], model.measurement, reduce=False)
             ts_full = _lib.TrajSetHandle(h_full, [np.asarray(trajs[0][:])], np.asarray(model.localization_error)[None, :])
-
-            def canon():
-                _lib.logl_segments_device(h_full, ts_full, n, k + 1, d_start.data_ptr(), d_state.data_ptr(), 0,
-                                          d_out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream, path='dense')
-            cdt, ckms, cname = timed(canon, 3, 1)
+            seg_h[0], seg_h[1] = h_full, ts_full
+            cdt, ckms, cname = timed(lambda: seg_step('dense'), 3, 1)
             ccan, cexe = _lib.flop_count(h_full, ts_full, n, path='dense')
             full_out = d_out[:n].cpu().numpy().copy()
+            seg_h[0], seg_h[1] = h, ts
             result['canonical_path'] = {
                 'what': 'dense path without reduction: the reference recursion itself on all %d monomers' % h_full.query(_lib.Q_N),
                 'value': n * 3 / cdt, 'unit': 'evals/s', 'kernel': cname, 'kernel_ms': ckms, 'bound': 'mfma' if 'mfma' in cname else 'valu',
                 'achieved': cexe / (ckms * 1e-3) / 1e12, 'unit_achieved': 'TFLOP/s fp64',
                 'frac': cexe / (ckms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
-            }
-            step(args.path)
-            torch.cuda.synchronize()
-            result['canonical_path']['max_abs_diff_vs_default_path'] = float(np.max(np.abs(full_out - d_out[:n].cpu().numpy())))
+                'max_abs_diff_vs_default_path': float(np.max(np.abs(full_out - default_results())))}
         if not args.no_cpu_baseline:
             base, ref_out = cpu_baseline(rank, n, T, k, args.states)
             result['cpu_baseline'] = base
-            step(args.path)
-            torch.cuda.synchronize()
-            got = d_out[:len(ref_out)].cpu().numpy()
+            got = default_results()[:len(ref_out)]
             result['parity_max_abs_diff_vs_cpu_baseline'] = float(np.max(np.abs(got - ref_out)))
             result['speedup_vs_cpu_baseline'] = value / base['value']
             if args.cpu_allcores:

@@ -65,6 +65,7 @@ _SIGNATURES = {
     'bild_logl_segments': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, _ip, _ip, _ip, ctypes.c_uint, _dp]),
     'bild_logl_st': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, _dp, _vp, _ip, ctypes.c_uint, _dp]),
     'bild_logl_st_to_device': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, _dp, _vp, _ip, ctypes.c_uint, _vp, _vp]),
+    'bild_logl_st_device': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, _vp, _vp, _vp, ctypes.c_uint, _vp, _vp, _vp]),
     'bild_segments_from_st': (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, _ip, ctypes.c_int64, _dp, _vp, _ip, _ip]),
     'bild_logl_profiles': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int64, _ip, _ip, ctypes.c_uint, _dp]),
     'bild_logl_segments_device': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, _vp, _vp, _vp,
@@ -356,6 +357,16 @@ def logl_segments_device(model, ts, n, K1, d_seg_start, d_seg_state, d_traj_id, 
                                           _vp(stream) if stream else None, _vp(d_out)))
 
 
+def logl_st_device(model, ts, n, K1, d_ss, d_thetas, d_out, d_traj_id=0, stream=0, path='auto', d_status=0, split=True, states=True):
+    """
+    the sampler's (s, theta) rows resident in HBM (raw device pointers: float64 n x K1, uint8 n x K1), results to d_out;
+    asynchronous on `stream` (bild_logl_st_device)
+    """
+    check(lib().bild_logl_st_device(model._h, ts._h, n, K1, _vp(d_ss), _vp(d_thetas), _vp(d_traj_id) if d_traj_id else None,
+                                    _flags(path, split=split, states=states), _vp(stream) if stream else None, _vp(d_out),
+                                    _vp(d_status) if d_status else None))
+
+
 def flop_count(model, ts, n, traj_id=None, path='auto'):
     can, exe = ctypes.c_double(0), ctypes.c_double(0)
     tid = None if traj_id is None else i32(traj_id)
@@ -364,7 +375,8 @@ def flop_count(model, ts, n, traj_id=None, path='auto'):
 
 
 def kernel_timing(enable):
-    check(lib().bild_kernel_timing(1 if enable else 0))
+    """ False / 0: off; True / 1: events around every launch; p > 1: around every p-th launch """
+    check(lib().bild_kernel_timing(int(enable)))
 
 
 def kernel_timing_read():

@@ -117,7 +117,8 @@ struct PinnedBuf {
 // kernel timing (bench.py roofline leg)
 std::atomic<int32_t *> g_frames_task{nullptr}; // diagnostics: bild_debug_frames_per_task
 std::mutex g_time_mu;
-bool g_time_on = false;
+int g_time_on = 0; // 0: off; p >= 1: every p-th launch is bracketed by events (sampling keeps the events out of most steps)
+uint64_t g_time_count = 0;
 std::vector<std::pair<hipEvent_t, hipEvent_t>> g_time_events;
 std::vector<std::pair<hipEvent_t, hipEvent_t>> g_walk_events; // the table walk in front of a split launch (walk.hip)
 std::string g_time_name;
@@ -171,6 +172,7 @@ struct bild_model {
     // The block serves every launch on the stream that used it first (launches on one stream run one after another);
     // launches on other streams get a stream-ordered allocation of their own.
     mutable DeviceBuf ws_work;
+    mutable DeviceBuf ws_lists; // same rule: segment lists the walk kernel writes for the frame loop ((s, theta) input resident in HBM)
     mutable hipStream_t work_stream = nullptr;
     mutable bool work_stream_set = false;
     mutable int work_set = 0;
@@ -913,6 +915,10 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
         const int64_t tasks_for_geometry = may_split ? 1 : n * ts.dstar_max;
         if (!geometry_for(m.NPm[mode], mode, tasks_for_geometry, ts.means_max, &geom))
             return fail(BILD_ERR_UNSUPPORTED, "no kernel for %d rows", m.NPm[mode]);
+        if (may_split) {
+            Geometry lg{};
+            if (listed_geometry(geom, &lg)) geom = lg;
+        }
         lds = lds_bytes(m, geom, mode);
         if (lds > 160 * 1024)
             return fail(BILD_ERR_UNSUPPORTED, "model tables need %zu bytes of LDS (> 160 KiB): too many states (%d) for chain length %d", lds, m.S, m.n);
@@ -921,6 +927,11 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
     const size_t walk_bytes = fam == kVector ? (size_t)geom.W * (64 / geom.G) * kWalkDoubles * sizeof(double) : 0;
     const bool walk_fits = fam == kVector && K1 <= kSegLds && lds + walk_bytes <= (size_t)48 * 1024 && !getenv("BILD_NO_WALK_PLAN");
 
+    bool timing; // this launch is bracketed by events (bild_kernel_timing: every p-th one) and counts the frames it runs
+    {
+        std::lock_guard<std::mutex> lk(g_time_mu);
+        timing = g_time_on > 0 && !tl_building && (g_time_count++ % (uint64_t)g_time_on) == 0;
+    }
     KParams p{};
     fill_params(m, ts, mode, p);
     p.ntasks = n * ts.dstar_max;
@@ -971,10 +982,7 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
                 }
             }
         }
-        {
-            std::lock_guard<std::mutex> lk(g_time_mu);
-            if (g_time_on) p.frames_run = m.d_frames;
-        }
+        if (timing) p.frames_run = m.d_frames;
         p.frames_task = g_frames_task.load();
     }
     // d* > 1: one partial result per (sample, covariance chain), summed by a second kernel.  The buffer belongs to
@@ -985,11 +993,6 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
         HIP_TRY(hipMallocAsync((void **)&target, (size_t)p.ntasks * sizeof(double), st));
     }
     p.out = target;
-    bool timing;
-    {
-        std::lock_guard<std::mutex> lk(g_time_mu);
-        timing = g_time_on;
-    }
 
     // ---- the table walk in front of the frame loop (walk.hip) -----------------------------------------------------
     // With all tables in place a task is a handful of lookups unless it holds a chain of three or more close switches:
@@ -1002,11 +1005,37 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
     const bool no_split = no_split_env || (flags & BILD_NO_SPLIT);
     const bool split = fam == kVector && mode == kModal && K1 <= kSplitMaxK1 && !tl_building && !no_split && p.trans != nullptr &&
                        p.walk_lds && ts.d_prefix_L != nullptr && p.ntasks <= (int64_t)INT_MAX;
-    int32_t *work_alloc = nullptr;
+    int32_t *work_alloc = nullptr, *lists_alloc = nullptr;
     auto release = [&]() {
         if (ts.dstar_max > 1) (void)hipFreeAsync(target, st);
         if (work_alloc) (void)hipFreeAsync(work_alloc, st);
+        if (lists_alloc) (void)hipFreeAsync(lists_alloc, st);
     };
+    if (st_in && (!d_seg_start || !d_seg_state)) {
+        // (s, theta) rows resident in HBM and no room given for the lists the frame loop reads: the model's block on the
+        // stream that owns it, else an allocation of this call
+        const size_t bytes = 2 * (size_t)n * K1 * sizeof(int32_t);
+        int32_t *lists = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(m.mu);
+            if (!m.work_stream_set) {
+                m.work_stream = st;
+                m.work_stream_set = true;
+            }
+            if (m.work_stream == st && m.ws_lists.reserve(bytes) == BILD_OK) lists = (int32_t *)m.ws_lists.ptr;
+        }
+        if (!lists) {
+            if (hipMallocAsync((void **)&lists_alloc, bytes, st) != hipSuccess) {
+                release();
+                return fail(BILD_ERR_NOMEM, "segment lists: out of device memory");
+            }
+            lists = lists_alloc;
+        }
+        d_seg_start = lists;
+        d_seg_state = lists + (size_t)n * K1;
+        p.seg_start = d_seg_start;
+        p.seg_state = d_seg_state;
+    }
     if (split || st_in) {
         WalkParams w{};
         w.trajs = ts.d_descs;
@@ -1115,6 +1144,7 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
         return fail(BILD_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
     }
     if (work_alloc) (void)hipFreeAsync(work_alloc, st);
+    if (lists_alloc) (void)hipFreeAsync(lists_alloc, st);
     if (timing) {
         HIP_TRY(hipEventRecord(e1, st));
         std::lock_guard<std::mutex> lk(g_time_mu);
@@ -1372,11 +1402,17 @@ int run_staged(const bild_model *m, const bild_trajset *ts, int64_t n, int K1, c
     SplitIn sp;
     // the status word lives in pinned host memory the device writes to directly: the host reads it after its synchronisation
     int32_t *h_status = (int32_t *)((char *)m->h_out.ptr + (size_t)n * sizeof(double));
+    // Batches of up to 50 000 rows on one trajectory: the walk kernel reads the (s, theta) rows straight out of the pinned
+    // block over PCIe (450 KB for the 10k batch) -- no host-to-device copy to enqueue and wait for: 136 -> 130 us per call.
+    // BILD_IN_VIA_COPY=1: always through a copy in HBM.
+    static const bool in_copy = getenv("BILD_IN_VIA_COPY") != nullptr;
+    const bool direct_in = !in_copy && st_payload && !traj_id && n <= 50000;
     if (st_payload) {
         d_start = (int32_t *)(d_base + copy_cap);
         d_state = d_start + nseg;
-        sp.d_ss = (const double *)(d_base + kStagedHeader);
-        sp.d_thetas = (const int8_t *)(d_base + kStagedHeader + nseg * sizeof(double));
+        const char *in_base = direct_in ? h_base : d_base;
+        sp.d_ss = (const double *)(in_base + kStagedHeader);
+        sp.d_thetas = (const int8_t *)(in_base + kStagedHeader + nseg * sizeof(double));
         if (d_out_user) { // nobody waits: the verdict stays with the model until bild_logl_st_status asks
             if (!m->h_status.ptr) {
                 std::lock_guard<std::mutex> lk(m->mu);
@@ -1392,9 +1428,12 @@ int run_staged(const bild_model *m, const bild_trajset *ts, int64_t n, int K1, c
         d_start = (int32_t *)(d_base + kStagedHeader);
         d_state = d_start + nseg;
     }
-    double *d_out = d_out_user ? d_out_user : (double *)m->ws_out.ptr;
+    // Results of a host-buffer call: the kernels write them straight into the pinned block (80 KB of posted writes over
+    // PCIe for the 10k batch) -- no device-to-host copy to launch and wait for.  BILD_OUT_VIA_COPY=1: through HBM and a copy.
+    static const bool out_via_copy = getenv("BILD_OUT_VIA_COPY") != nullptr;
+    double *d_out = d_out_user ? d_out_user : (out_via_copy ? (double *)m->ws_out.ptr : (double *)m->h_out.ptr);
     hipStream_t st = d_out_user ? st_user : m->stream;
-    HIP_TRY(hipMemcpyAsync(d_base, h_base, in_bytes, hipMemcpyHostToDevice, st));
+    if (!direct_in) HIP_TRY(hipMemcpyAsync(d_base, h_base, in_bytes, hipMemcpyHostToDevice, st));
     if (!ordered && !st_payload) {
         const int32_t *on_device = nullptr;
         if (device_order(*m, *ts, n, K1, d_start, d_tid, flags, st, &on_device) == 0) d_order = on_device;
@@ -1411,7 +1450,7 @@ int run_staged(const bild_model *m, const bild_trajset *ts, int64_t n, int K1, c
         return BILD_OK;
     }
     clk.lap(2);
-    HIP_TRY(hipMemcpyAsync(m->h_out.ptr, d_out, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (out_via_copy) HIP_TRY(hipMemcpyAsync(m->h_out.ptr, d_out, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     clk.lap(3);
     if (st_payload && h_status[0] != 0)
@@ -1533,6 +1572,7 @@ int bild_model_destroy(bild_model *m)
     m->ws_out.release();
     m->ws_sched.release();
     m->ws_work.release();
+    m->ws_lists.release();
     m->h_in.release();
     m->h_out.release();
     m->h_status.release();
@@ -1620,6 +1660,19 @@ int bild_trajset_create(const bild_model *m, int n_traj, const int32_t *T, const
         delete ts;
         return code;
     };
+    // the largest steady-state variance of the observable w.x over the states: with s2 the scale of an innovation
+    double wCw_max = 0.0;
+    {
+        const int N = m->N;
+        for (int s_ = 0; s_ < m->S; ++s_) {
+            const double *C0 = m->C0.data() + (size_t)s_ * N * N;
+            double q = 0.0;
+            for (int i = 0; i < N; ++i)
+                for (int jj = 0; jj < N; ++jj) q += m->w[i] * C0[(size_t)i * N + jj] * m->w[jj];
+            wCw_max = std::max(wCw_max, q);
+        }
+    }
+    std::vector<double> xscales((size_t)n_traj, 0.0);
     hipError_t he = hipMalloc((void **)&ts->d_x, xd.size() * sizeof(double));
     if (he != hipSuccess) return cleanup(fail(BILD_ERR_NOMEM, "hipMalloc failed: %s", hipGetErrorString(he)));
     ts->d_zeros = ts->d_x + (size_t)(total + (int64_t)kPadRows * n_traj) * d;
@@ -1642,6 +1695,7 @@ int bild_trajset_create(const bild_model *m, int n_traj, const int32_t *T, const
         }
         td.nvalid = nvalid;
         td.xscale = xscale;
+        xscales[(size_t)j] = xscale;
         ts->all_valid = ts->all_valid && nvalid == T[j];
         // np.unique(err, return_inverse=True): sorted unique values (pyx:145)
         double uniq[kDStore];
@@ -1672,6 +1726,7 @@ int bild_trajset_create(const bild_model *m, int n_traj, const int32_t *T, const
         }
         td.dstar = nchains;
         td.nuniq = nu;
+        for (int u = 0; u < nchains; ++u) td.mscale[u] = std::min(xscales[(size_t)j], 6.0 * std::sqrt(td.s2[u] + wCw_max));
         nu = nchains;
         ts->dstar_max = std::max(ts->dstar_max, nu);
         for (int u = 0; u < nu; ++u) ts->means_max = std::max(ts->means_max, (int)td.ndims[u]);
@@ -1754,6 +1809,32 @@ int bild_logl_segments_device_ordered(const bild_model *m, const bild_trajset *t
             return fail(BILD_ERR_INVALID, "device descriptors rejected: %s (e.g. sample %d)", what[h_err[0] & 7], h_err[1]);
     }
     return launch_batch(*m, *ts, n, K1, d_seg_start, d_seg_state, d_traj_id, d_order, flags, st, d_out);
+}
+
+int bild_logl_st_device(const bild_model *m, const bild_trajset *ts, int64_t n, int K1, const double *d_ss, const uint8_t *d_thetas,
+                        const int32_t *d_traj_id, unsigned flags, void *hip_stream, double *d_out, int32_t *d_status)
+{
+    int rc = check_eval_args(m, ts, n, K1);
+    if (rc) return rc;
+    if (n == 0) return BILD_OK;
+    if (!d_ss || !d_thetas || !d_out) return fail(BILD_ERR_INVALID, "NULL device buffer");
+    if (K1 > kSplitMaxK1) return fail(BILD_ERR_UNSUPPORTED, "(s, theta) rows resident in HBM: at most %d segments per candidate (got %d)", kSplitMaxK1, K1);
+    SplitIn sp;
+    sp.d_ss = d_ss;
+    sp.d_thetas = (const int8_t *)d_thetas;
+    // the verdict on the rows: the caller's word, or a scratch word of the model nobody reads (rows that are no points on
+    // the simplex still get NaN)
+    if (d_status) {
+        sp.status = d_status;
+    } else {
+        std::lock_guard<std::mutex> lk(m->mu);
+        if (!m->h_status.ptr) {
+            if ((rc = m->h_status.reserve(64))) return rc;
+            std::memset(m->h_status.ptr, 0, 64);
+        }
+        sp.status = (int32_t *)m->h_status.ptr + 8;
+    }
+    return launch_batch(*m, *ts, n, K1, nullptr, nullptr, d_traj_id, nullptr, flags, (hipStream_t)hip_stream, d_out, &sp);
 }
 
 int bild_logl_segments_device(const bild_model *m, const bild_trajset *ts, int64_t n, int K1, const int32_t *d_seg_start,
@@ -2098,7 +2179,8 @@ int bild_kernel_timing_read_walk(double *total_ms, int64_t *launches)
 int bild_kernel_timing(int enable)
 {
     std::lock_guard<std::mutex> lk(g_time_mu);
-    g_time_on = enable != 0;
+    g_time_on = enable < 0 ? 0 : enable;
+    g_time_count = 0;
     return BILD_OK;
 }
 

@@ -20,6 +20,7 @@ int launch_logl(const Geometry &, int, const KParams &, int, size_t, void *) { r
 int launch_reduce_partials(const double *, double *, int64_t, int, void *) { return 1; }
 int launch_validate(const int32_t *, const int32_t *, const int32_t *, const int32_t *, int64_t, int, int, int, int *, void *) { return 1; }
 bool builder_geometry(int, Geometry *) { return false; }
+bool listed_geometry(const Geometry &, Geometry *) { return false; }
 bool dense_mfma_supported(int NP) { return NP % 4 == 0 && NP >= 4 && NP <= 24; }
 int launch_logl_dense_mfma(int, const KParams &, void *) { return 1; }
 bool modal_mfma_supported(int NP) { return NP == 36 || NP == 40; }

@@ -47,7 +47,9 @@ struct TrajDesc {
     int32_t nvalid;          // frames with data
     int32_t nuniq;           // distinct localization errors (the reference's d*, pyx:145), <= dstar
     int64_t prefix_rec0;     // first record of this trajectory in the prefix table (records, see prefix_record_doubles)
-    double xscale;           // largest |coordinate| of the data: absolute floor of the mean-vector comparison
+    double xscale;           // largest |coordinate| of the data
+    double mscale[kChains];  // absolute floor of the mean-vector comparison of chain e: min(xscale, 6 sqrt(S_e)), S_e the largest
+                             // steady-state innovation variance of the chain (see logl_kernel: convergence check)
     int64_t trans0;          // first entry of this trajectory in the transient table
     int64_t strans0;         // first record of this trajectory in the transient state table
 };
@@ -206,6 +208,9 @@ int padded_rows(int n_rows);
 // task when fewer mean vectors are needed); env BILD_GEOM=<id> overrides.
 bool geometry_for(int NP, int mode, int64_t ntasks, int means, Geometry *g);
 const char *kernel_name(const Geometry &g, int mode);
+// the geometry of the frame loop over the work lists of a split launch, where it differs from `from` (same layout, same
+// arithmetic, another register budget); false: keep `from`
+bool listed_geometry(const Geometry &from, Geometry *g);
 // the geometry whose kernel is also compiled as the builder of the prefix table (KParams::prefix_dump)
 bool builder_geometry(int NP, Geometry *g);
 // dense recursion on the fp64 matrix pipe (dense_mfma.hip): NP a multiple of 4, <= 24

@@ -420,7 +420,9 @@ __device__ __forceinline__ void logl_body(const KParams &p)
         // measurement vector in the current basis.  Row layout, jump instantiation: NOT kept in registers -- the same for
         // all lanes of a row, it is read from the state header in LDS at the top of every update (five 16-byte reads, behind
         // the predict), and the twenty registers go to the event paths, which otherwise spill around the frame loop
-        constexpr bool kWqFromLds = ROW && JUMP;
+        // (at two waves per SIMD -- the geometry of the frame loop over the work lists, id 23 -- there are registers enough:
+        // a lone wave then does not wait for five LDS reads in front of every update)
+        constexpr bool kWqFromLds = ROW && JUMP && OCC >= 3;
         double wq[NP];
         // modal predict  C'_ij <- lam_i lam_j C'_ij + sig_i delta_ij,  M'_i <- lam_i M'_i  as ONE
         // fma per entry: L[q][i] = lam_i * (lam_c or 1), sgd[i] = sig_c on the own diagonal entry
@@ -989,7 +991,11 @@ __device__ __forceinline__ void logl_body(const KParams &p)
 #pragma unroll
                 for (int q = 0; q < CPL; ++q) {
                     if (!hasImg[q]) continue;
-                    double dev = 0.0, ref = isM[q] ? td->xscale : 0.0;
+                    // (mean columns: the floor is the scale of the DATA as far as the model can explain it -- for data drawn
+                    // from the model the largest coordinate itself, 4-5 standard deviations of the innovation; for data the model
+                    // did not produce (an offset, outliers) the innovations e grow with the data, the log-likelihood error of a
+                    // deviation d is ~ 20 |e| d / S, and the floor must not grow with them: TrajDesc::mscale)
+                    double dev = 0.0, ref = isM[q] ? td->mscale[e] : 0.0;
 #pragma unroll
                     for (int i = 0; i < NP; i += 2) {
                         const double2 r2 = *reinterpret_cast<const double2 *>(rec + cidx[q] * NP + i);
@@ -1188,6 +1194,11 @@ int launch_geom(int mode, const KParams &p, int grid, size_t lds, hipStream_t st
 //    no LDS all-gather in the frame loop, 20 registers less.  Same operations in the same order as the packed
 //    layouts, hence bit-identical results (checked: max |diff| = 0 against (1, 13) on every batch size tried).
 //    10 000 x T=1000: 485 -> 448 us; a lone wave (3 000 tasks) 285 -> 237 us; with missing frames 522 -> 484 us
+//    Id 23 is the same layout bounded for TWO waves per SIMD: the frame loop over the work lists of a split launch
+//    (walk.hip), which is latency-bound -- a few hundred tasks, one per wave, the launch as long as its longest chain --
+//    and gains 6-9 % from the larger register budget (no spills around the frame loop, the measurement vector in
+//    registers instead of five LDS reads per frame: 63.6 -> 59.6 us at k = 4, 116 -> 105 us at k = 8); for whole batches
+//    run frame by frame three waves per SIMD stay the better geometry (r02_occ2_again.txt).
 //    (profiles/r02_row_layout.txt).  Listed before the packed geometry with the same number of tasks per wave, so the
 //    modal path picks it whenever three mean vectors are needed; with fewer, (1, 11) / (1, 12) carry 5 tasks per wave.
 // seventh field: layout (0 packed, 1 matrix-instruction block, 2 row); last field: which paths may select the geometry
@@ -1206,6 +1217,7 @@ int launch_geom(int mode, const KParams &p, int grid, size_t lds, hipStream_t st
     X(19, 10, 1, 11, 4, 3, 0, 3)  \
     X(20, 10, 1, 12, 4, 3, 0, 3)  \
     X(21, 10, 1, 16, 4, BILD_ROW_OCC, 2, 2)  \
+    X(23, 10, 1, 16, 4, 2, 2, 0)  \
     X(3, 10, 1, 13, 4, 3, 0, 3)   \
     X(4, 10, 2, 7, 4, 2, 0, 3)    \
     X(22, 12, 1, 16, 4, 2, 2, 2)  \
@@ -1275,10 +1287,21 @@ bool geometry_for(int NP, int mode, int64_t ntasks, int means, Geometry *g)
     return true;
 }
 
+bool listed_geometry(const Geometry &from, Geometry *g)
+{
+    if (from.id != 21 || getenv("BILD_GEOM")) return false;
+    for (const Geometry &c : kGeoms)
+        if (c.id == 23) {
+            *g = c;
+            return true;
+        }
+    return false;
+}
+
 bool builder_geometry(int NP, Geometry *g)
 {
     for (const Geometry &c : kGeoms)
-        if (c.NP == NP && c.CPL == 1 && c.G == NP + kDMax && c.id != 15 && c.id != 16 && c.id != 21 && c.id != 22) {
+        if (c.NP == NP && c.CPL == 1 && c.G == NP + kDMax && c.id != 15 && c.id != 16 && c.id != 21 && c.id != 22 && c.id != 23) {
             *g = c;
             return true;
         }

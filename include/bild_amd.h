@@ -172,6 +172,19 @@ int bild_trajset_destroy(bild_trajset *ts);
  *
  * All-missing trajectory -> 0.0 (semantics of MSRouse_logL_py.py:90-94).  NaN/Inf in a
  * result is passed through, never trapped.
+ *
+ * REPRODUCIBILITY CONTRACT (differs from the reference, whose MSRouse_logL is a pure function of its three arguments):
+ *   - on ONE trajectory set a result is a pure function of (candidate, trajectory): bit-identical whatever the batch it
+ *     is part of, the order of the batch, the entry point (host buffers, device buffers, (s, theta) rows or segment
+ *     lists), the stream, the launch geometry, what was evaluated before, and with or without the split launch / the
+ *     transient state table (BILD_NO_SPLIT, BILD_NO_STATES);
+ *   - the same (candidate, trajectory) pair on two DIFFERENT trajectory sets (the trajectory alone / among hundreds of
+ *     others) may take its sums from different tables -- which of them are built depends on the size of the set -- and
+ *     agrees to rounding, |delta| ~ 1e-11 at |logL| ~ 3e4, not to the bit;
+ *   - BILD_NO_JUMP (or BILD_NO_PREFIX) gives the frame-by-frame result, which IS a pure function of its inputs on any
+ *     set; the default differs from it by ~1e-11 (bound and measurements: DESIGN.md section 2, tests/test_gpu_adversarial.py).
+ * Against the reference's Cython kernel every path agrees to |delta| < 1e-8 (observed 1e-10; the reference's two own
+ * kernels differ by 2.6e-10 among themselves).
  */
 
 /* host buffers in, host buffer out; synchronous */
@@ -224,6 +237,17 @@ int bild_logl_segments_device(const bild_model *m, const bild_trajset *ts, int64
                               const int32_t *d_seg_start, const int32_t *d_seg_state,
                               const int32_t *d_traj_id, unsigned flags, void *hip_stream,
                               double *d_out);
+
+/* The sampler's own (s, theta) rows, RESIDENT IN HBM: d_ss (n x K1 float64), d_thetas (n x K1 uint8), d_traj_id (n int32
+ * or NULL).  Everything FixedkSampler.logL does for a batch happens on the device, asynchronously on `hip_stream`: switch
+ * frames as st2profile computes them (bild/amis.py:685-688), cleaning, the table walk, the frame loop for the chains of
+ * close switches, results to d_out (n doubles).  K1 <= 16.  Rows that are no points on the simplex (negative / non-finite
+ * interval lengths, a state >= S) get NaN; d_status (2 ints in device-visible memory, zeroed by the caller, or NULL)
+ * then holds {1, such a row}.  This is the entry bench.py times as `value`: candidates in HBM as the sampler produced
+ * them, nothing converted, ordered or scheduled beforehand. */
+int bild_logl_st_device(const bild_model *m, const bild_trajset *ts, int64_t n, int K1,
+                        const double *d_ss, const uint8_t *d_thetas, const int32_t *d_traj_id,
+                        unsigned flags, void *hip_stream, double *d_out, int32_t *d_status);
 
 /* ------------------------------------------------- prefix table and launch order -------
  * Until its first switch a candidate's filter state depends only on (trajectory, localization-error chain, initial
@@ -325,6 +349,8 @@ int bild_flop_count(const bild_model *m, const bild_trajset *ts, int64_t n,
 /* name and accumulated device time (ms, HIP events on the launch stream) of the kernel the
  * most recent evaluations ran; resets the accumulator.  Used by bench.py for the roofline
  * figure.  Timing is off unless enabled. */
+/* enable = 0: off; 1: every launch is bracketed by events; p > 1: every p-th launch (the events themselves cost a few
+ * microseconds per launch: sampling keeps them out of most steps of a timed region) */
 int bild_kernel_timing(int enable);
 int bild_kernel_timing_read(double *total_ms, int64_t *launches, char *name, int name_len);
 /* the same for the table-walk kernel that precedes the frame loop in a split launch (see "split launches" above) */

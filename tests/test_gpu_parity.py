@@ -1104,3 +1104,118 @@ def test_many_states(built_lib, S):
         with pytest.raises(_lib.BildAmdError) as info:
             big.logL_st_batch(ss[:4], thetas[:4] % 2, traj)
         assert info.value.code == _lib.ERR_UNSUPPORTED and 'too many states' in str(info.value)
+
+
+def test_st_rows_resident_in_hbm(built_lib):
+    """
+    bild_logl_st_device: the sampler's (s, theta) rows lie in HBM (float64 / uint8) and everything happens on the device --
+    switch frames as st2profile computes them, cleaning, table walk, frame loop.  Bit-identical to the host-buffer seam
+    (`bild_logl_st`), to the segment entry on the host-converted lists, on the caller's stream and on a second one, for one
+    trajectory and for several (traj_id, two localization-error chains); a row that is no point on the simplex gets NaN and
+    is reported in the status word, the other rows are unaffected.
+    """
+    import torch
+    import bild_amd
+    from bild_amd import _lib
+    from bild_amd.profiles import segments_from_st
+    rng = np.random.default_rng(321)
+    dev = torch.device('cuda', 0)
+    for case in ('one', 'many_dstar2'):
+        if case == 'one':
+            model = bild_amd.MultiStateRouse(20, 1, 5, d=3, localization_error=0.1)
+            Ts, n, k = [600], 6000, 5
+        else:
+            model = bild_amd.MultiStateRouse(20, 1, 5, d=3, localization_error=[0.1, 0.25, 0.1])
+            Ts, n, k = [150, 333, 611], 5000, 3
+        trajs = [model.trajectory_from_loopingprofile(H.random_profile(rng, T, 2, max(T // 4, 2)), missing_frames=0.05, rng=rng) for T in Ts]
+        tid = rng.integers(len(trajs), size=n).astype(np.int32)
+        ss, thetas = H.candidate_profiles(rng, n, k, 2)
+        h, ts = model.handle(), model.trajset(trajs)
+        want = _lib.logl_st(h, ts, ss, thetas, tid)
+        a = np.zeros((n, k + 1), dtype=np.int32)
+        for j, T in enumerate(Ts):
+            a[tid == j] = segments_from_st(ss[tid == j], thetas[tid == j], T)[0]
+        assert np.array_equal(_lib.logl_segments(h, ts, a, thetas.astype(np.int32), tid), want)
+        d_ss = torch.from_numpy(ss).to(dev)
+        d_th = torch.from_numpy(thetas.astype(np.uint8)).to(dev)
+        d_tid = torch.from_numpy(tid).to(dev)
+        out = torch.zeros(n, dtype=torch.float64, device=dev)
+        status = torch.zeros(2, dtype=torch.int32, device=dev)
+        side = torch.cuda.Stream()
+        for stream in (torch.cuda.current_stream(), side, torch.cuda.current_stream()):
+            for split in (True, False):
+                out.fill_(0.0)
+                torch.cuda.synchronize()
+                _lib.logl_st_device(h, ts, n, k + 1, d_ss.data_ptr(), d_th.data_ptr(), out.data_ptr(), d_traj_id=d_tid.data_ptr(),
+                                    stream=stream.cuda_stream, d_status=status.data_ptr(), split=split)
+                torch.cuda.synchronize()
+                assert np.array_equal(out.cpu().numpy(), want), (case, split)
+        assert status.cpu().numpy()[0] == 0
+        bad = ss.copy()
+        bad[11, 1] = np.nan
+        bad[12, 0] = -0.3
+        d_bad = torch.from_numpy(bad).to(dev)
+        _lib.logl_st_device(h, ts, n, k + 1, d_bad.data_ptr(), d_th.data_ptr(), out.data_ptr(), d_traj_id=d_tid.data_ptr(),
+                            d_status=status.data_ptr())
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        assert np.isnan(got[11]) and np.isnan(got[12]) and status.cpu().numpy()[0] == 1 and status.cpu().numpy()[1] in (11, 12)
+        keep = np.ones(n, dtype=bool)
+        keep[[11, 12]] = False
+        assert np.array_equal(got[keep], want[keep])
+        with pytest.raises(_lib.BildAmdError):
+            _lib.logl_st(h, ts, bad, thetas, tid)
+
+
+def test_schedule_rejects_rows_it_cannot_index(built_lib):
+    """ bild_schedule_segments validates like bild_logl_segments: a decreasing row used to index its work histogram out of range """
+    import bild_amd
+    from bild_amd import _lib
+    rng = np.random.default_rng(2)
+    model = bild_amd.MultiStateRouse(20, 1, 5, d=3, localization_error=0.1)
+    traj = model.trajectory_from_loopingprofile(H.random_profile(rng, 1000, 2, 200), rng=rng)
+    h, ts = model.handle(), model.trajset(traj)
+    a = np.array([[0, 500, 100], [0, 10, 20]], dtype=np.int32)
+    b = np.array([[0, 1, 0], [0, 1, 0]], dtype=np.int32)
+    _lib.logl_segments(h, ts, a[1:], b[1:])            # the set's tables exist now
+    with pytest.raises(_lib.BildAmdError):
+        _lib.schedule_segments(h, ts, a, b)
+    with pytest.raises(_lib.BildAmdError):
+        _lib.schedule_segments(h, ts, a[1:], np.array([[0, 7, 0]], dtype=np.int32))
+    assert len(_lib.schedule_segments(h, ts, a[1:], b[1:])) == 1
+
+
+def test_trajset_cache_notices_edits_in_place(built_lib):
+    """
+    The trajectory-set cache is keyed by identity and guarded by a cheap look at the contents (address, shape, a strided
+    subsample, the number of NaNs): masking frames or rescaling the data in place leads to a fresh upload instead of stale
+    likelihoods; a trajectory-like that builds a new array on every access is keyed by its contents and uploaded once.
+    """
+    import bild_amd
+    rng = np.random.default_rng(4)
+    model = bild_amd.MultiStateRouse(20, 1, 5, d=3, localization_error=0.1)
+    traj = model.trajectory_from_loopingprofile(H.random_profile(rng, 300, 2, 60), rng=rng)
+    prof = H.random_profile(rng, 300, 2, 60)
+    first = model.logL(prof, traj)
+    ts0 = model.trajset(traj)
+    assert model.trajset(traj) is ts0                       # unchanged: the same resident set
+    data = traj[:]
+    data[40:50] = np.nan                                      # in place: masked frames
+    masked = model.logL(prof, traj)
+    assert model.trajset(traj) is not ts0 and masked != first
+    fresh = bild_amd.Trajectory(data.copy(), localization_error=traj.localization_error)
+    assert masked == model.logL(prof, fresh)
+    data *= 1.5                                               # in place: rescaled
+    assert model.logL(prof, traj) == model.logL(prof, bild_amd.Trajectory(data.copy(), localization_error=traj.localization_error))
+
+    class Fresh:                                              # t[:] materialises a new array on every access
+        def __init__(self, arr):
+            self._a, self.localization_error = arr, None
+        def __len__(self):
+            return len(self._a)
+        def __getitem__(self, key):
+            return self._a.copy()[key]
+    lazy = Fresh(data.copy())
+    v0 = model.logL(prof, lazy)
+    ts1 = model.trajset(lazy)
+    assert model.trajset(lazy) is ts1 and model.logL(prof, lazy) == v0
