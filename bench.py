@@ -367,7 +367,9 @@ def main():
                         'longest chain of close switches, run frame by frame by ONE wavefront (DESIGN.md section 4)',
         'tables': {'bytes': prefix_bytes, 'build_ms_device': prefix_ms,
                    'note': 'prefix / transient / transient-state / pair tables of the trajectory set, built once by the likelihood '
-                           'kernel itself at the first evaluation (device time of the builds; `first_call` below has the wall time)'},
+                           'kernel itself at the first evaluation.  build_ms_device is the FIRST set of the process: its builder '
+                           'launches include loading their code objects (once per process); `first_call` below times a second '
+                           'set, warm'},
         'traffic': traffic,
         'traffic_note': traffic_note,
         'algorithmic_bytes_per_launch': alg_bytes + table_bytes,

@@ -171,11 +171,30 @@ struct bild_model {
     // launch before, which has finished -- for the launch after: no launch of its own is needed to zero sixteen integers.
     // The block serves every launch on the stream that used it first (launches on one stream run one after another);
     // launches on other streams get a stream-ordered allocation of their own.
-    mutable DeviceBuf ws_work;
-    mutable DeviceBuf ws_lists; // same rule: segment lists the walk kernel writes for the frame loop ((s, theta) input resident in HBM)
-    mutable hipStream_t work_stream = nullptr;
-    mutable bool work_stream_set = false;
-    mutable int work_set = 0;
+    // Two such blocks: the first for the model's own stream (host-buffer calls), the second for the first other stream that
+    // launches on the model (a caller's stream: bench.py, dist.ShardedModel); launches on further streams allocate.
+    struct WorkSlot {
+        DeviceBuf ws_work;
+        DeviceBuf ws_lists; // same rule: segment lists the walk kernel writes for the frame loop ((s, theta) input resident in HBM)
+        hipStream_t stream = nullptr;
+        bool taken = false;
+        int work_set = 0;
+    };
+    mutable WorkSlot slots[2];
+    // the block of stream `st`, or null (caller holds `mu`)
+    WorkSlot *slot_for(hipStream_t st) const
+    {
+        if (st == stream && stream != nullptr) {
+            slots[0].stream = st;
+            slots[0].taken = true;
+            return &slots[0];
+        }
+        if (!slots[1].taken) {
+            slots[1].stream = st;
+            slots[1].taken = true;
+        }
+        return slots[1].stream == st ? &slots[1] : nullptr;
+    }
     mutable PinnedBuf h_status; // (s, theta) rows refused on the device by calls nobody waited for: sticky until bild_logl_st_status
 };
 
@@ -1018,11 +1037,8 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
         int32_t *lists = nullptr;
         {
             std::lock_guard<std::mutex> lk(m.mu);
-            if (!m.work_stream_set) {
-                m.work_stream = st;
-                m.work_stream_set = true;
-            }
-            if (m.work_stream == st && m.ws_lists.reserve(bytes) == BILD_OK) lists = (int32_t *)m.ws_lists.ptr;
+            bild_model::WorkSlot *slot = m.slot_for(st);
+            if (slot && slot->ws_lists.reserve(bytes) == BILD_OK) lists = (int32_t *)slot->ws_lists.ptr;
         }
         if (!lists) {
             if (hipMallocAsync((void **)&lists_alloc, bytes, st) != hipSuccess) {
@@ -1060,23 +1076,21 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
             const size_t list_bytes = (size_t)kWorkBuckets * (size_t)p.ntasks * sizeof(int32_t);
             {
                 std::lock_guard<std::mutex> lk(m.mu);
-                if (!m.work_stream_set) {
-                    m.work_stream = st;
-                    m.work_stream_set = true;
-                }
-                if (m.work_stream == st) {
-                    if (m.ws_work.cap < kWorkHeader + list_bytes) {
+                bild_model::WorkSlot *slot = m.slot_for(st);
+                if (slot) {
+                    DeviceBuf &ws_work = slot->ws_work;
+                    if (ws_work.cap < kWorkHeader + list_bytes) {
                         // (hipFree inside waits for the device: nothing still reads the old block)
                         // (the memset on the launch's own stream: a plain hipMemset is not ordered against a non-blocking stream)
-                        if (m.ws_work.reserve(kWorkHeader + list_bytes) != BILD_OK || hipMemsetAsync(m.ws_work.ptr, 0, kWorkHeader, st) != hipSuccess) {
+                        if (ws_work.reserve(kWorkHeader + list_bytes) != BILD_OK || hipMemsetAsync(ws_work.ptr, 0, kWorkHeader, st) != hipSuccess) {
                             release();
                             return fail(BILD_ERR_NOMEM, "work lists: allocation of %zu bytes failed", kWorkHeader + list_bytes);
                         }
                     }
-                    d_work = (int32_t *)m.ws_work.ptr + kWorkBuckets * m.work_set;
-                    w.work_counts_next = (int32_t *)m.ws_work.ptr + kWorkBuckets * (1 - m.work_set);
-                    m.work_set = 1 - m.work_set;
-                    d_lists = (int32_t *)((char *)m.ws_work.ptr + kWorkHeader);
+                    d_work = (int32_t *)ws_work.ptr + kWorkBuckets * slot->work_set;
+                    w.work_counts_next = (int32_t *)ws_work.ptr + kWorkBuckets * (1 - slot->work_set);
+                    slot->work_set = 1 - slot->work_set;
+                    d_lists = (int32_t *)((char *)ws_work.ptr + kWorkHeader);
                 }
             }
             if (!d_work) {
@@ -1108,15 +1122,13 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
         if (timing) {
             HIP_TRY(hipEventCreate(&w0));
             HIP_TRY(hipEventCreate(&w1));
-            HIP_TRY(hipEventRecord(w0, st));
         }
-        const int wrc = launch_walk(w, (void *)st);
+        const int wrc = launch_walk(w, (void *)st, (void *)w0, (void *)w1); // (timed: the events ride on the dispatch)
         if (wrc != 0) {
             release();
             return fail(BILD_ERR_HIP, "walk kernel launch failed: %s", hipGetErrorString((hipError_t)wrc));
         }
         if (timing) {
-            HIP_TRY(hipEventRecord(w1, st));
             std::lock_guard<std::mutex> lk(g_time_mu);
             g_walk_events.emplace_back(w0, w1);
         }
@@ -1130,15 +1142,18 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
     const int64_t max_blocks = split ? (work_blocks > 0 ? work_blocks : 256 * std::max(geom.OCC, 1)) : 256 * 16;
     const int grid = (int)std::min<int64_t>(std::max<int64_t>(blocks, 1), max_blocks);
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    // timed launches of the vector kernels carry their events on the dispatch (start / end of the kernel itself); the tile
+    // kernels are bracketed by recorded events (milliseconds long: the brackets' own latency does not matter there)
+    const bool ride = fam == kVector;
     if (timing) {
         HIP_TRY(hipEventCreate(&e0));
         HIP_TRY(hipEventCreate(&e1));
-        HIP_TRY(hipEventRecord(e0, st));
+        if (!ride) HIP_TRY(hipEventRecord(e0, st));
     }
     int lrc = fam == kWide         ? launch_logl_wide(m.NP, p, grid, (void *)st)
               : fam == kModalTiles ? launch_logl_modal_mfma(m.NPm[kModal], p, (void *)st)
               : fam == kDenseTiles ? launch_logl_dense_mfma(m.NPm[kDense], p, (void *)st)
-                                   : launch_logl(geom, mode, p, grid, lds, (void *)st);
+                                   : launch_logl(geom, mode, p, grid, lds, (void *)st, timing ? (void *)e0 : nullptr, timing ? (void *)e1 : nullptr);
     if (lrc != 0) {
         release();
         return fail(BILD_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
@@ -1146,7 +1161,7 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
     if (work_alloc) (void)hipFreeAsync(work_alloc, st);
     if (lists_alloc) (void)hipFreeAsync(lists_alloc, st);
     if (timing) {
-        HIP_TRY(hipEventRecord(e1, st));
+        if (!ride) HIP_TRY(hipEventRecord(e1, st));
         std::lock_guard<std::mutex> lk(g_time_mu);
         g_time_events.emplace_back(e0, e1);
         g_time_name = fam == kWide ? "logl_wide_kernel" : fam == kModalTiles ? "logl_modal_mfma_kernel" : fam == kDenseTiles ? "logl_dense_mfma_kernel" : kernel_name(geom, mode);
@@ -1571,8 +1586,10 @@ int bild_model_destroy(bild_model *m)
     m->ws_in.release();
     m->ws_out.release();
     m->ws_sched.release();
-    m->ws_work.release();
-    m->ws_lists.release();
+    for (bild_model::WorkSlot &sl : m->slots) {
+        sl.ws_work.release();
+        sl.ws_lists.release();
+    }
     m->h_in.release();
     m->h_out.release();
     m->h_status.release();

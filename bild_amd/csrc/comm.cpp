@@ -48,12 +48,16 @@ bool load_rccl()
 {
     std::lock_guard<std::mutex> lk(g_mu);
     if (g_rccl.handle) return true;
-    const char *candidates[] = {g_path.empty() ? nullptr : g_path.c_str(), getenv("BILD_AMD_RCCL"), "librccl.so.1", "librccl.so",
-                                "/opt/rocm/lib/librccl.so.1"};
+    // BILD_AMD_RCCL_ONLY=1: nothing but the library named by bild_comm_library / BILD_AMD_RCCL is tried (tests of the
+    // path without RCCL; deployments that must not pick up whatever librccl the loader finds)
+    const bool only_named = getenv("BILD_AMD_RCCL_ONLY") != nullptr;
+    const char *candidates[] = {g_path.empty() ? nullptr : g_path.c_str(), getenv("BILD_AMD_RCCL"), only_named ? nullptr : "librccl.so.1",
+                                only_named ? nullptr : "librccl.so", only_named ? nullptr : "/opt/rocm/lib/librccl.so.1"};
     void *h = nullptr;
     // an RCCL that is already in the process wins (two copies would each bring their own HIP runtime)
-    for (const char *name : {"librccl.so", "librccl.so.1"})
-        if (!h) h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+    if (!only_named)
+        for (const char *name : {"librccl.so", "librccl.so.1"})
+            if (!h) h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
     for (const char *c : candidates)
         if (!h && c) h = dlopen(c, RTLD_NOW | RTLD_GLOBAL);
     if (!h) {

@@ -168,7 +168,7 @@ struct WalkParams {
     int32_t *frames_task;           // non-null (diagnostics): a task finished here ran no frame
     int32_t debug;                  // timing experiments only (BILD_WALK_DEBUG; wrong results): 1 no pair loads, 2 no append, 4 no loads at all
 };
-int launch_walk(const WalkParams &p, void *stream);
+int launch_walk(const WalkParams &p, void *stream, void *ev_start = nullptr, void *ev_stop = nullptr);
 
 // launch geometry for a padded chain length
 struct Geometry {
@@ -196,7 +196,9 @@ constexpr int state_header_doubles(int NP) { return 3 * NP; }
 constexpr int kWalkDoubles = 3 * kSegLds;
 
 // host-callable launchers implemented in kernels.hip
-int launch_logl(const Geometry &g, int mode, const KParams &p, int grid, size_t lds_bytes, void *stream);
+// (ev_start / ev_stop: hipEvent_t attached to the dispatch of a timed launch, or null)
+int launch_logl(const Geometry &g, int mode, const KParams &p, int grid, size_t lds_bytes, void *stream, void *ev_start = nullptr,
+                void *ev_stop = nullptr);
 int launch_reduce_partials(const double *partial, double *out, int64_t n, int dstar_max, void *stream);
 // d_err: 2 ints (verdict, a sample that shows it) followed, when `order` is given, by n hit counters; zeroed by the caller
 int launch_validate(const int32_t *seg_start, const int32_t *seg_state, const int32_t *traj_id, const int32_t *order, int64_t n,

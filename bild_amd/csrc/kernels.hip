@@ -37,6 +37,7 @@
 // * sum_t log S_t is accumulated as a running product with exponent extraction
 //   (frexp) and one log per task, instead of one log per frame.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <limits.h>
 #include <math.h>
 #include <stdlib.h>
@@ -1125,14 +1126,18 @@ __global__ void validate_kernel(const int32_t *__restrict__ seg_start, const int
 }
 
 template <int NP, int CPL, int G, int W, int OCC, int LAY>
-int launch_geom(int mode, const KParams &p, int grid, size_t lds, hipStream_t st)
+int launch_geom(int mode, const KParams &p, int grid, size_t lds, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1)
 {
     constexpr int kThreads = 64 * W;
     hipError_t err;
     auto go = [&](auto k) -> int {
         err = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess) return (int)err;
-        hipLaunchKernelGGL(k, dim3(grid), dim3(kThreads), lds, st, p);
+        // timed launches: the events are attached to the dispatch itself (start and end of the kernel as the profiler sees
+        // them), not recorded around it -- events AROUND a launch add the latency of two barrier packets, 12-14 us, to a
+        // kernel of this size
+        if (ev0 && ev1) hipExtLaunchKernelGGL(k, dim3(grid), dim3(kThreads), (unsigned)lds, st, ev0, ev1, 0, p);
+        else hipLaunchKernelGGL(k, dim3(grid), dim3(kThreads), lds, st, p);
         return (int)hipGetLastError();
     };
     // G != 0 (an external force on the chain) never occurs through the reference's entry points
@@ -1310,12 +1315,13 @@ bool builder_geometry(int NP, Geometry *g)
 
 const char *kernel_name(const Geometry &, int mode) { return mode == kModal ? "logl_kernel<modal>" : "logl_kernel<dense>"; }
 
-int launch_logl(const Geometry &g, int mode, const KParams &p, int grid, size_t lds, void *stream)
+int launch_logl(const Geometry &g, int mode, const KParams &p, int grid, size_t lds, void *stream, void *ev_start, void *ev_stop)
 {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipEvent_t ev0 = reinterpret_cast<hipEvent_t>(ev_start), ev1 = reinterpret_cast<hipEvent_t>(ev_stop);
     switch (g.id) {
 #define X(ID, NP, CPL, G, W, OCC, LAY, MODES) \
-    case ID: return launch_geom<NP, CPL, G, W, OCC, LAY>(mode, p, grid, lds, st);
+    case ID: return launch_geom<NP, CPL, G, W, OCC, LAY>(mode, p, grid, lds, st, ev0, ev1);
         BILD_GEOMETRIES(X)
 #undef X
     default: return -1;

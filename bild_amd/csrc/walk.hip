@@ -22,6 +22,7 @@
 // (BILD_NO_SPLIT) for every task -- those finished here by construction of the walk, the others because the frame-loop
 // kernel starts them from scratch.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <limits.h>
 #include <stdlib.h>
 
@@ -303,14 +304,15 @@ __global__ void __launch_bounds__(kWalkThreads) walk_kernel(const WalkParams p)
 }
 
 template <bool ST>
-int launch_st(const WalkParams &p, hipStream_t st)
+int launch_st(const WalkParams &p, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1)
 {
     const int64_t ntasks = p.n * p.dstar_max;
     const unsigned grid = (unsigned)((ntasks + kWalkThreads - 1) / kWalkThreads);
     // one instantiation per list length (k = K1 - 1 switches per candidate)
 #define BILD_WALK_CASE(KMAX)                                                                  \
     if (p.K1 == KMAX) {                                                                       \
-        hipLaunchKernelGGL((walk_kernel<KMAX, ST>), dim3(grid), dim3(kWalkThreads), 0, st, p);          \
+        if (ev0 && ev1) hipExtLaunchKernelGGL((walk_kernel<KMAX, ST>), dim3(grid), dim3(kWalkThreads), 0, st, ev0, ev1, 0, p); \
+        else hipLaunchKernelGGL((walk_kernel<KMAX, ST>), dim3(grid), dim3(kWalkThreads), 0, st, p);      \
         return (int)hipGetLastError();                                                        \
     }
     BILD_WALK_CASE(1)
@@ -335,13 +337,14 @@ int launch_st(const WalkParams &p, hipStream_t st)
 
 } // namespace
 
-int launch_walk(const WalkParams &p, void *stream)
+int launch_walk(const WalkParams &p, void *stream, void *ev_start, void *ev_stop)
 {
     if (p.n <= 0) return 0;
     if (const char *dbg = getenv("BILD_WALK_DEBUG")) const_cast<WalkParams &>(p).debug = atoi(dbg);
     if (p.n * p.dstar_max > (int64_t)INT_MAX) return (int)hipErrorInvalidValue; // task indices in the work lists are int32
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    return p.ss ? launch_st<true>(p, st) : launch_st<false>(p, st);
+    hipEvent_t ev0 = reinterpret_cast<hipEvent_t>(ev_start), ev1 = reinterpret_cast<hipEvent_t>(ev_stop);
+    return p.ss ? launch_st<true>(p, st, ev0, ev1) : launch_st<false>(p, st, ev0, ev1);
 }
 
 } // namespace bild

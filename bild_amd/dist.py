@@ -221,6 +221,8 @@ class ShardedModel:
         comm.allgather(local.ptr, gathered.ptr, m, stream=0)          # default stream: ordered behind the kernel
         host = gathered.to_host(m * comm.world)                       # the one device -> host copy of the step
         self.host_copies += 1
+        if hi > lo:
+            self._model.check_st_rows()
         return np.concatenate([host[r * m:r * m + sizes[r]] for r in range(comm.world)])
 
     def logL_st_batch(self, ss, thetas, traj):
@@ -252,6 +254,8 @@ class ShardedModel:
             dist.all_gather_into_tensor(gathered, local, group=self._group)      # same stream: ordered behind the kernel
             host = gathered.cpu().numpy()                                        # the one device -> host copy of the step
             self.host_copies += 1
+            if hi > lo:
+                self._model.check_st_rows()      # rows the device refused (no points on the simplex): raises, as `logL` does
             return np.concatenate([host[r * m:r * m + sizes[r]] for r in range(world)])
         local = np.asarray(self._model.logL_st_batch(ss[lo:hi], thetas[lo:hi], traj), dtype=np.float64) if hi > lo \
             else np.empty(0)

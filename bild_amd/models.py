@@ -265,6 +265,13 @@ class MultiStateRouse(MultiStateModel):
         """
         _lib.logl_st_to_device(self.handle(), self.trajset(traj), ss, thetas, d_out, stream=stream, path=self.path)
 
+    def check_st_rows(self):
+        """
+        `logL_st_batch_to_device` waits for nothing and cannot refuse a row that is no point on the simplex (it gets NaN):
+        this waits for the pending calls and raises if one of their rows was refused (bild_logl_st_status)
+        """
+        _lib.logl_st_status(self.handle())
+
     def logL_st(self, s, theta, traj):
         """ the per-sample hook the reference sampler prefers when present (bild/amis.py:734-736) """
         return float(self.logL_st_batch(np.asarray(s)[None, :], np.asarray(theta)[None, :], traj)[0])

@@ -145,3 +145,36 @@ def test_modal_unavailable_for_nonsymmetric_propagator(built_lib):
     assert h.query(_lib.Q_MODAL_OK) == 0 and h.query(_lib.Q_NEFF) == 6
     with pytest.raises(_lib.BildAmdError):
         h.export(_lib.X_Q, 0)
+
+
+def test_collective_without_rccl_is_refused_not_crashed(tmp_path):
+    """
+    No RCCL to be found (the named library does not exist and nothing else is tried): the communicator calls return
+    BILD_ERR_UNSUPPORTED with a message, as include/bild_amd.h promises -- they used to build that message from two
+    dlerror() calls, the second of which returns NULL.  A fresh process: the library caches a loaded RCCL.
+    """
+    import subprocess
+    import sys
+    code = r'''
+import ctypes, os, sys
+sys.path.insert(0, sys.argv[1])
+os.environ["BILD_AMD_RCCL_ONLY"] = "1"
+os.environ["BILD_AMD_RCCL"] = os.path.join(sys.argv[2], "no_such_librccl.so")
+from bild_amd import _lib
+lib = _lib.lib()
+lib.bild_comm_library(os.path.join(sys.argv[2], "neither.so").encode())
+buf = ctypes.create_string_buffer(128)
+rc = lib.bild_comm_unique_id(buf, 128)
+msg = lib.bild_last_error().decode()
+out = ctypes.c_void_p()
+rc2 = lib.bild_comm_create(buf, 1, 0, ctypes.byref(out))
+print(rc, rc2, msg)
+sys.exit(0 if (rc == _lib.ERR_UNSUPPORTED and rc2 == _lib.ERR_UNSUPPORTED and "not found" in msg) else 1)
+'''
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    if os.environ.get('BILD_AMD_LIB'):
+        env['BILD_AMD_LIB'] = os.environ['BILD_AMD_LIB']
+    res = subprocess.run([sys.executable, '-c', code, root, str(tmp_path)], capture_output=True, text=True, env=env, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr

@@ -1219,3 +1219,45 @@ def test_trajset_cache_notices_edits_in_place(built_lib):
     v0 = model.logL(prof, lazy)
     ts1 = model.trajset(lazy)
     assert model.trajset(lazy) is ts1 and model.logL(prof, lazy) == v0
+
+
+def test_to_device_call_followed_by_a_host_call(built_lib):
+    """
+    bild_logl_st_to_device waits for nothing: its kernels still read the model's staging blocks and work lists when the call
+    returns.  The next call on the model -- here a host-buffer call with DIFFERENT candidates, right behind it -- must not
+    overwrite them early (the event of the first call is recorded behind its last kernel).  Both results against the
+    oracle; and a row that is no point on the simplex in a to_device call is reported by bild_logl_st_status.
+    """
+    import torch
+    import bild_amd
+    from bild_amd import _lib
+    rng = np.random.default_rng(808)
+    T, n, k = 800, 20000, 6
+    model = bild_amd.MultiStateRouse(20, 1, 5, d=3, localization_error=0.1)
+    traj = model.trajectory_from_loopingprofile(H.random_profile(rng, T, 2, 150), rng=rng)
+    h, ts = model.handle(), model.trajset(traj)
+    ss1, th1 = H.candidate_profiles(rng, n, k, 2)
+    ss2, th2 = H.candidate_profiles(rng, n, k, 2)
+    want1, want2 = _lib.logl_st(h, ts, ss1, th1), _lib.logl_st(h, ts, ss2, th2)
+    dev = torch.device('cuda', 0)
+    out = torch.zeros(n, dtype=torch.float64, device=dev)
+    side = torch.cuda.Stream()
+    for _ in range(5):
+        out.fill_(0.0)
+        torch.cuda.synchronize()
+        _lib.logl_st_to_device(h, ts, ss1, th1, out.data_ptr(), stream=side.cuda_stream)
+        got2 = _lib.logl_st(h, ts, ss2, th2)                 # immediately: other candidates through the same staging blocks
+        torch.cuda.synchronize()
+        assert np.array_equal(got2, want2) and np.array_equal(out.cpu().numpy(), want1)
+    _lib.logl_st_status(h)                                   # nothing was refused
+    bad = ss1.copy()
+    bad[5, 2] = -1.0
+    _lib.logl_st_to_device(h, ts, bad, th1, out.data_ptr(), stream=side.cuda_stream)
+    with pytest.raises(_lib.BildAmdError):
+        _lib.logl_st_status(h)
+    _lib.logl_st_status(h)                                   # the verdict is forgotten once it has been read
+    assert np.isnan(out.cpu().numpy()[5])
+    pick = rng.choice(n, 12, replace=False)
+    from oracle import oracle
+    ref = oracle.logl_batch(model.arrays(), model.measurement, model.localization_error, traj[:], H.expand(ss1[pick], th1[pick], T))
+    assert np.max(np.abs(ref - want1[pick])) < TOL

@@ -25,7 +25,7 @@ def build(specs):
         name, _, flags = spec.partition(':')
         out = os.path.join(VDIR, f'libbild_amd_{name}.so')
         cmd = ['hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-shared'] + flags.split() + \
-              [os.path.join(CSRC, f) for f in ('api.cpp', 'amis_host.cpp', 'comm.cpp', 'kernels.hip', 'wide.hip', 'dense_mfma.hip',
+              [os.path.join(CSRC, f) for f in ('api.cpp', 'amis_host.cpp', 'comm.cpp', 'kernels.hip', 'walk.hip', 'wide.hip', 'dense_mfma.hip',
                                                'modal_mfma.hip', 'amis_device.hip', 'schedule.hip')] + ['-o', out]
         procs.append((name, subprocess.Popen(cmd)))
     for name, p in procs:

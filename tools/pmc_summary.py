@@ -18,7 +18,7 @@ def main(dirs):
             agg = collections.defaultdict(lambda: collections.defaultdict(list))
             meta = {}
             for r in csv.DictReader(open(f)):
-                m = re.search(r'(logl_\w+<[^>]*>|reduce_partials_kernel|validate_kernel)', r['Kernel_Name'])
+                m = re.search(r'(logl_\w+<[^>]*>|walk_kernel<[^>]*>|pass_[abc]_kernel|draw_kernel|reduce_partials_kernel|validate_kernel)', r['Kernel_Name'])
                 if not m:
                     continue
                 k = m.group(1)

@@ -1,5 +1,5 @@
 """
-Strong-scaling projection from ONE GPU: per-rank kernel time of the shards an N-GPU run would hand to each rank, plus the
+Strong-scaling projection from ONE GPU: per-rank device time (table walk + frame loop) of the shards an N-GPU run would hand to each rank, plus the
 latency of the step's one collective (measured here with RCCL at world size 1: the floor of the call, not of the wire).
 
   configs[1]: 10 000 candidates x 1 trajectory, split into contiguous shards of 10000 / N
@@ -12,7 +12,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, torch, torch.distributed as dist, helpers as H, bild_amd
 from bild_amd import _lib
-from bild_amd.profiles import segments_from_st
 
 T, k = 1000, 4
 dev = torch.device('cuda', 0)
@@ -21,36 +20,36 @@ os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER
 dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
 
 
-def kernel_and_wall(model, trajs, ss, thetas, tid, reps=20, use_order=True):
+def kernel_and_wall(model, trajs, ss, thetas, tid, reps=20):
+    """ device time of both kernels (table walk + frame loop) and launch-to-done wall time of one step, rows resident in HBM """
     h = model.handle()
     ts = model.trajset(trajs if tid is not None else trajs[0])
-    a, b = segments_from_st(ss, thetas, T)
-    n = len(a)
-    da, db = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    n = len(ss)
+    _lib.logl_st(h, ts, ss[:100], thetas[:100], None if tid is None else tid[:100])      # builds the tables
+    d_ss = torch.from_numpy(np.ascontiguousarray(ss)).to(dev)
+    d_th = torch.from_numpy(thetas.astype(np.uint8)).to(dev)
     dt_ = torch.from_numpy(tid).to(dev) if tid is not None else None
     out = torch.empty(n, dtype=torch.float64, device=dev)
-    d_order = [None]
     def go():
-        _lib.logl_segments_device(h, ts, n, k + 1, da.data_ptr(), db.data_ptr(), dt_.data_ptr() if dt_ is not None else 0,
-                                  out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream,
-                                  d_order=d_order[0].data_ptr() if d_order[0] is not None else 0)
-    go()                                                    # builds the tables the scheduler's estimate needs
-    torch.cuda.synchronize()
-    if use_order:                                           # as bench.py: the launch order computed once per resident batch
-        d_order[0] = torch.from_numpy(np.asarray(_lib.schedule_segments(h, ts, a, b, tid))).to(dev)
+        _lib.logl_st_device(h, ts, n, k + 1, d_ss.data_ptr(), d_th.data_ptr(), out.data_ptr(),
+                            d_traj_id=dt_.data_ptr() if dt_ is not None else 0, stream=torch.cuda.current_stream().cuda_stream)
     for _ in range(3):
         go()
     torch.cuda.synchronize()
-    _lib.kernel_timing(True)
     t0 = time.perf_counter()
     for _ in range(reps):
         go()
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t0) / reps
+    _lib.kernel_timing(True)
+    for _ in range(reps):
+        go()
+    torch.cuda.synchronize()
     _lib.kernel_timing(False)
     ms, c, _ = _lib.kernel_timing_read()
+    wms, wc = _lib.kernel_timing_read_walk()
     _lib.frames_run_read(h)
-    return ms / c * 1e-3, wall
+    return (ms / c + wms / max(wc, 1)) * 1e-3, wall
 
 
 def allgather_latency(n_local, world_equiv, reps=200):
@@ -68,7 +67,7 @@ def allgather_latency(n_local, world_equiv, reps=200):
 
 rng = np.random.default_rng(7)
 model = bild_amd.MultiStateRouse(20, 1., 5., d=3, localization_error=0.1)
-print("configs[1]: 10 000 candidates x 1 trajectory (T=1000, k=4), contiguous shards, scheduler's launch order")
+print("configs[1]: 10 000 candidates x 1 trajectory (T=1000, k=4), contiguous shards, (s, theta) rows resident in HBM")
 traj = model.trajectory_from_loopingprofile(H.random_profile(rng, T, 2, 200), rng=rng)
 ss, thetas = H.candidate_profiles(rng, 10000, k, 2)
 base = None
@@ -81,7 +80,7 @@ for N in (1, 2, 4, 8):
     print(f"  N={N}: {n:6d} candidates per rank: kernel {kt * 1e6:7.1f} us, launch-to-done {wall * 1e6:7.1f} us, all_gather(world 1, {n} doubles) "
           f"{ag * 1e6:5.1f} us -> step {step * 1e6:7.1f} us = {10000 / step / 1e6:6.1f} M evals/s, x{base / step:4.2f} of N=1")
 
-print("configs[2]: 256 trajectories x 1 000 candidates (T=1000, k=4), whole trajectories per rank, scheduler's launch order")
+print("configs[2]: 256 trajectories x 1 000 candidates (T=1000, k=4), whole trajectories per rank, (s, theta) rows resident in HBM")
 trajs = [model.trajectory_from_loopingprofile(H.random_profile(rng, T, 2, 200), rng=rng) for _ in range(256)]
 ss, thetas = H.candidate_profiles(rng, 256000, k, 2)
 base = None
