@@ -62,6 +62,7 @@ _SIGNATURES = {
     'bild_model_export': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, ctypes.c_int64]),
     'bild_trajset_create': (ctypes.c_int, [_vp, ctypes.c_int, _ip, _dp, _dp, ctypes.POINTER(_vp)]),
     'bild_trajset_destroy': (ctypes.c_int, [_vp]),
+    'bild_trajset_expect': (ctypes.c_int, [_vp, ctypes.c_int64]),
     'bild_logl_segments': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, _ip, _ip, _ip, ctypes.c_uint, _dp]),
     'bild_logl_st': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, _dp, _vp, _ip, ctypes.c_uint, _dp]),
     'bild_logl_st_to_device': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, _dp, _vp, _ip, ctypes.c_uint, _vp, _vp]),
@@ -233,6 +234,10 @@ class TrajSetHandle:
         self.n_traj = len(arrs)
         self._h = _vp()
         check(lib().bild_trajset_create(model._h, self.n_traj, iptr(self.T), dptr(x), dptr(err), ctypes.byref(self._h)))
+
+    def expect(self, evaluations):
+        """ declare, before the first evaluation, how many evaluations the set will see (bild_trajset_expect) """
+        check(lib().bild_trajset_expect(self._h, int(evaluations)))
 
     def __del__(self):
         if getattr(self, '_h', None) and _lib is not None:

@@ -230,12 +230,17 @@ struct bild_trajset {
     mutable int64_t trans2_entries = 0;
     mutable double trans2_build_ms = 0.0;
     mutable int gap_max = 0;              // gaps 1 .. gap_max - 1 are in the pair table
+    // the caller's declaration of how many evaluations the set will see (bild_trajset_expect; < 0: none given): which tables
+    // are worth their build -- a property of the set and of that declaration, never of the call history
+    mutable std::atomic<int64_t> expected_evals{-1};
     mutable double *d_strans = nullptr;   // transient state table (common.h), filled by the launch that builds the transient table
     mutable int64_t strans_records = 0;
     mutable int trans_m_max = 0;          // longest converged transient of the single table
     mutable int trans_m_typ = 48;         // typical frames-to-convergence of the table's entries (90th percentile): the scheduler's yardstick
 };
 constexpr int kZeroPad = 8;
+// bild_trajset_expect: below these many declared evaluations the prefix (+ transient) tables / the pair and state tables are not built
+constexpr int64_t kExpectPrefix = 300, kExpectPairs = 3000;
 // set by ensure_transients / ensure_pairs around their own launch: this launch FILLS a table (1: transients, 2: pairs) --
 // a thread-local marker, not a bit of `flags`, so that no caller's flags can ever ask for it
 thread_local int tl_building = 0;
@@ -635,6 +640,7 @@ int ensure_prefix(const bild_model &m, const bild_trajset &ts, hipStream_t st)
     if (ts.prefix_state != 0) return BILD_OK;
     ts.prefix_state = -1;
     if (getenv("BILD_NO_PREFIX")) return BILD_OK;
+    if (ts.expected_evals >= 0 && ts.expected_evals < kExpectPrefix) return BILD_OK; // a few hundred evaluations: cheaper frame by frame
     const int NP = m.NPm[kModal];
     Geometry geom{};
     if (!builder_geometry(NP, &geom)) return BILD_OK;
@@ -761,7 +767,7 @@ int ensure_transients(const bild_model &m, const bild_trajset &ts, hipStream_t s
     // the state table beside it (common.h: a chain of close switches starts at its second switch): an optimisation with a
     // budget -- T x S (S - 1) x 64 records of ~1.1 KB per trajectory and chain, 141 MB for one 2-state trajectory of 1000 frames
     double *d_states = nullptr;
-    if (ok && !getenv("BILD_NO_STATES")) {
+    if (ok && !getenv("BILD_NO_STATES") && !(ts.expected_evals >= 0 && ts.expected_evals < kExpectPairs)) {
         const size_t sbytes = (size_t)ts.strans_records * prefix_record_doubles(m.NPm[kModal]) * sizeof(double);
         static const size_t budget = getenv("BILD_STATES_MAX_BYTES") ? (size_t)atoll(getenv("BILD_STATES_MAX_BYTES")) : ((size_t)64 << 30);
         if (sbytes <= budget && hipMemGetInfo(&free_b, &total_b) == hipSuccess && sbytes <= free_b / 3) {
@@ -840,6 +846,7 @@ int ensure_pairs(const bild_model &m, const bild_trajset &ts, hipStream_t st)
     if (ts.trans2_state != 0) return BILD_OK;
     ts.trans2_state = -1;
     if (ts.trans_state != 1 || getenv("BILD_NO_PAIRS") || m.S < 2) return BILD_OK;
+    if (ts.expected_evals >= 0 && ts.expected_evals < kExpectPairs) return BILD_OK; // (the second-level tables pay from a few thousand evaluations on)
     const int S = m.S, G = std::min(64, ts.trans_m_max);
     if (G < 2) return BILD_OK;
     int64_t nb = 0;
@@ -1769,6 +1776,14 @@ int bild_trajset_create(const bild_model *m, int n_traj, const int32_t *T, const
     he = hipMemcpy(ts->d_descs, ts->descs.data(), (size_t)n_traj * sizeof(TrajDesc), hipMemcpyHostToDevice);
     if (he != hipSuccess) return cleanup(fail(BILD_ERR_HIP, "hipMemcpy failed: %s", hipGetErrorString(he)));
     *out = ts;
+    return BILD_OK;
+}
+
+int bild_trajset_expect(bild_trajset *ts, int64_t evaluations)
+{
+    if (!ts) return fail(BILD_ERR_INVALID, "NULL handle");
+    if (ts->prefix_state != 0) return fail(BILD_ERR_INVALID, "the trajectory set has been evaluated on already: declare the expected use first");
+    ts->expected_evals = evaluations;
     return BILD_OK;
 }
 

@@ -182,19 +182,22 @@ class MultiStateRouse(MultiStateModel):
         self._handle = None
         self._trajsets.clear()
 
-    def trajset(self, trajs):
+    def trajset(self, trajs, expect=None):
         """
         Device-resident set of trajectories (uploaded once, reused across AMIS steps).
 
         trajs : a trajectory or a list of trajectories
+        expect : optional, the number of evaluations the set will see in total (`bild_trajset_expect`; honoured when the set
+            is created by this call): a few single evaluations per trajectory are cheaper without the set's tables
 
         The cache is keyed by the IDENTITY of the trajectory objects, and an entry is trusted while the address and shape
-        of each trajectory's data, the localization errors in force and a cheap content guard (a strided subsample of
-        64 values plus the number of NaN entries) are unchanged: a lookup costs microseconds.  In-place edits that the
-        guard can see (masking frames with NaN, rescaling, refilling a preallocated array) therefore lead to a fresh
-        upload and fresh tables; an edit of single values between the guard's sample points is NOT noticed -- call
-        `invalidate()` after editing data in place.  Trajectory-likes whose ``t[:]`` builds a new array on every
-        access are keyed by a hash of their contents instead, so that they are not uploaded again on every call.
+        of each trajectory's data, the localization errors in force and a content guard (the sum of the bit patterns of
+        all values; a strided subsample of 65 536 of them for longer data) are unchanged: a lookup costs microseconds.
+        In-place edits (masking frames with NaN, rescaling, refilling a preallocated array, changing single values)
+        therefore lead to a fresh upload and fresh tables; only for data of more than 65 536 values can an edit between
+        the guard's sample points go unnoticed -- call `invalidate()` after editing such data in place.  Trajectory-likes
+        whose ``t[:]`` builds a new array on every access are keyed by a hash of their contents instead, so that they are
+        not uploaded again on every call.
         """
         single = not isinstance(trajs, (list, tuple))
         items = (trajs,) if single else tuple(trajs)
@@ -208,6 +211,8 @@ class MultiStateRouse(MultiStateModel):
                 return ts
         noises = [np.frombuffer(p[2], dtype=np.float64) for p in prints]
         ts = _lib.TrajSetHandle(self.handle(), arrs, np.stack(noises))
+        if expect is not None:
+            ts.expect(expect)
         self._trajsets[key] = (ts, items, prints)   # `items` keeps the objects (and their ids) alive
         while len(self._trajsets) > 8:
             self._trajsets.popitem(last=False)
@@ -218,15 +223,21 @@ class MultiStateRouse(MultiStateModel):
         out, arrs = [], []
         for t in items:
             view = t[:]
-            a = as_array(t)
+            a = view if (type(view) is np.ndarray and view.dtype == np.float64 and view.ndim == 2 and view.flags.c_contiguous) \
+                else as_array(t)
             arrs.append(a)
             noise = np.ascontiguousarray(self._get_noise(t), dtype=np.float64).tobytes()
-            stable = isinstance(view, np.ndarray) and isinstance(t[:], np.ndarray) and \
-                t[:].__array_interface__['data'][0] == view.__array_interface__['data'][0]
+            addr = view.__array_interface__['data'][0] if isinstance(view, np.ndarray) else None
+            # `t[:]` of an ndarray or of this package's Trajectory is a view of one buffer; anything else is asked twice
+            stable = addr is not None and (type(t) in (np.ndarray, Trajectory) or
+                                           (isinstance(t[:], np.ndarray) and t[:].__array_interface__['data'][0] == addr))
             if stable:
-                flat = a.reshape(-1)
-                guard = (flat[::max(1, flat.size // 64)].tobytes(), int(np.count_nonzero(flat != flat)))
-                out.append((view.__array_interface__['data'][0], a.shape, noise, guard))
+                # the guard: the sum of the bit patterns -- every value takes part (NaNs included, which an ordinary sum would
+                # drown in); beyond 65 536 values a strided subsample of that many
+                bits = a.reshape(-1).view(np.uint64)
+                if bits.size > 65536:
+                    bits = bits[::bits.size // 65536 + 1]
+                out.append((addr, a.shape, noise, int(bits.sum())))
             else:   # no stable buffer to identify the data by: the contents are the key
                 out.append((None, a.shape, noise, hash(a.tobytes())))
         return out, arrs

@@ -154,6 +154,13 @@ int bild_model_export(const bild_model *m, int what, int s, int s2, double *buf,
 int bild_trajset_create(const bild_model *m, int n_traj, const int32_t *T,
                         const double *x, const double *loc_err, bild_trajset **out);
 int bild_trajset_destroy(bild_trajset *ts);
+/* Optional, before the first evaluation on the set: how many evaluations the caller expects to run on it in total.  The
+ * tables of a set (see "prefix table" below) are built at its first evaluation and cost about 2 ms per trajectory of
+ * 1000 frames; they pay from a few hundred evaluations on (prefix + transient tables: >= 300) resp. a few thousand (pair
+ * and state tables: >= 3000).  Without a declaration everything is built -- right for an AMIS run, wasteful for a
+ * handful of single evaluations per trajectory.  Which tables exist depends on the set and on this declaration alone,
+ * never on the call history: results stay reproducible (and agree between declarations to rounding, like between sets). */
+int bild_trajset_expect(bild_trajset *ts, int64_t evaluations);
 
 /* ---------------------------------------------------------------- evaluation -------
  * One call = one AMIS batch (bild/amis.py:717-739): n independent evaluations

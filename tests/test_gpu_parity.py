@@ -1187,8 +1187,8 @@ def test_schedule_rejects_rows_it_cannot_index(built_lib):
 
 def test_trajset_cache_notices_edits_in_place(built_lib):
     """
-    The trajectory-set cache is keyed by identity and guarded by a cheap look at the contents (address, shape, a strided
-    subsample, the number of NaNs): masking frames or rescaling the data in place leads to a fresh upload instead of stale
+    The trajectory-set cache is keyed by identity and guarded by a look at the contents (address, shape, the sum of the
+    bit patterns of the values): masking frames or rescaling the data in place leads to a fresh upload instead of stale
     likelihoods; a trajectory-like that builds a new array on every access is keyed by its contents and uploaded once.
     """
     import bild_amd
@@ -1205,6 +1205,9 @@ def test_trajset_cache_notices_edits_in_place(built_lib):
     assert model.trajset(traj) is not ts0 and masked != first
     fresh = bild_amd.Trajectory(data.copy(), localization_error=traj.localization_error)
     assert masked == model.logL(prof, fresh)
+    before = model.trajset(traj)
+    data[123, 1] += 1e-9                                      # in place: ONE value, by a hair
+    assert model.trajset(traj) is not before
     data *= 1.5                                               # in place: rescaled
     assert model.logL(prof, traj) == model.logL(prof, bild_amd.Trajectory(data.copy(), localization_error=traj.localization_error))
 
@@ -1261,3 +1264,30 @@ def test_to_device_call_followed_by_a_host_call(built_lib):
     from oracle import oracle
     ref = oracle.logl_batch(model.arrays(), model.measurement, model.localization_error, traj[:], H.expand(ss1[pick], th1[pick], T))
     assert np.max(np.abs(ref - want1[pick])) < TOL
+
+
+def test_declared_use_decides_which_tables_are_built(built_lib):
+    """
+    bild_trajset_expect: a set that will see a handful of evaluations builds no tables (cheaper frame by frame), a few
+    hundred build the prefix and transient tables, thousands (or no declaration) all of them.  The results agree to the
+    jumps' tolerance whatever was declared, and a declaration after the first evaluation is refused.
+    """
+    import bild_amd
+    from bild_amd import _lib
+    rng = np.random.default_rng(17)
+    model = bild_amd.MultiStateRouse(20, 1, 5, d=3, localization_error=0.1)
+    data = model.trajectory_from_loopingprofile(H.random_profile(rng, 500, 2, 100), rng=rng)
+    ss, thetas = H.candidate_profiles(rng, 400, 4, 2)
+    out, sizes = {}, {}
+    for expect in (10, 1000, 10 ** 6, None):
+        traj = bild_amd.Trajectory(data[:].copy(), localization_error=data.localization_error)
+        ts = model.trajset(traj, expect=expect)
+        out[expect] = _lib.logl_st(model.handle(), ts, ss, thetas)
+        sizes[expect] = _lib.prefix_info(ts)[0]
+        with pytest.raises(_lib.BildAmdError):
+            ts.expect(5)
+    assert sizes[10] == 0 < sizes[1000] < sizes[10 ** 6] == sizes[None]
+    assert np.array_equal(out[10 ** 6], out[None])
+    assert np.array_equal(out[10], _lib.logl_st(model.handle(), model.trajset(data), ss, thetas, prefix=False))
+    for expect in (1000, None):
+        assert np.max(np.abs(out[expect] - out[10])) < 1e-9
