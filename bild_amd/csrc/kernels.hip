@@ -458,8 +458,14 @@ __device__ __forceinline__ void logl_body(const KParams &p)
         load_state(s);
 
         // ---- initial condition: steady state of state profile[0] (pyx:160-163) ----
+        // (a task that starts from a table -- every task of the jump instantiation -- loads its state there: start_from)
         Cols<NP, CPL> col;
-        {
+        if (JUMP && p.prefix != nullptr && !p.no_jump) {
+#pragma unroll
+            for (int q = 0; q < CPL; ++q)
+#pragma unroll
+                for (int i = 0; i < NP; ++i) col.v[q][i] = 0.0;
+        } else {
             const double *__restrict__ sb = p.states + (size_t)s * SB;
 #pragma unroll
             for (int q = 0; q < CPL; ++q) {
