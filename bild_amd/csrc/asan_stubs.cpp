@@ -36,6 +36,4 @@ int amis_dev_draw(int, int, int64_t, uint64_t, uint64_t, const double *, const d
 int amis_dev_pass_a(const AmisView &, int64_t, int64_t, int64_t, double, double *, double *, double *, double *, double *, int *, void *, const uint8_t *, uint8_t *, int32_t *, int32_t *, int32_t *) { return 1; }
 int amis_dev_pass_b(const AmisView &, int64_t, double, int, const double *, double *, double *, int, void *) { return 1; }
 int amis_dev_pass_c(const AmisView &, int64_t, const double *, double, const double *, const double *, double *, int, void *) { return 1; }
-void *internal_model_stream(const bild_model *) { return nullptr; }
-int internal_logl_st_resident(const bild_model *, const bild_trajset *, int64_t, int, const double *, const uint8_t *, unsigned, double *, int32_t *, void **) { return 1; }
 } // namespace bild
