@@ -1032,6 +1032,7 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
     const bool split = fam == kVector && mode == kModal && K1 <= kSplitMaxK1 && !tl_building && !no_split && p.trans != nullptr &&
                        p.walk_lds && ts.d_prefix_L != nullptr && p.ntasks <= (int64_t)INT_MAX;
     int32_t *work_alloc = nullptr, *lists_alloc = nullptr;
+    bild_model::WorkSlot *used_slot = nullptr; // the persistent work-list block this launch alternates the counter set of
     auto release = [&]() {
         if (ts.dstar_max > 1) (void)hipFreeAsync(target, st);
         if (work_alloc) (void)hipFreeAsync(work_alloc, st);
@@ -1097,6 +1098,7 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
                     d_work = (int32_t *)ws_work.ptr + kWorkBuckets * slot->work_set;
                     w.work_counts_next = (int32_t *)ws_work.ptr + kWorkBuckets * (1 - slot->work_set);
                     slot->work_set = 1 - slot->work_set;
+                    used_slot = slot;
                     d_lists = (int32_t *)((char *)ws_work.ptr + kWorkHeader);
                 }
             }
@@ -1132,6 +1134,10 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
         }
         const int wrc = launch_walk(w, (void *)st, (void *)w0, (void *)w1); // (timed: the events ride on the dispatch)
         if (wrc != 0) {
+            if (used_slot) { // the walk never ran: the other counter set was not zeroed -- the next launch must not take it
+                std::lock_guard<std::mutex> lk(m.mu);
+                used_slot->work_set = 1 - used_slot->work_set;
+            }
             release();
             return fail(BILD_ERR_HIP, "walk kernel launch failed: %s", hipGetErrorString((hipError_t)wrc));
         }

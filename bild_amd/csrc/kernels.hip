@@ -127,15 +127,17 @@ struct Cols {
 // streamed column-major into the group's LDS image Tg (NC columns of NP doubles), two rows at
 // a time, so no second register image of A is needed.  X is row-major in LDS (dense propagator
 // or modal basis change); one X operand pair feeds 2*CPL FMAs.
-template <int NP, int CPL, typename XPtr>
+template <int NP, int CPL, bool ROOMY = false, typename XPtr>
 __device__ __forceinline__ void matvec_to_lds(XPtr X, const Cols<NP, CPL> &in, double *__restrict__ Tg,
                                               const int (&cidx)[CPL], const bool (&store)[CPL])
 {
     // rows per trip: two give each X operand pair 2*CPL independent FMAs; with a single column per
     // lane one row at a time keeps the operand registers of this (rare) path out of the budget of
-    // the frame loop
-    constexpr int R = (CPL == 1) ? 1 : 2;
-#pragma unroll 1
+    // the frame loop -- unless the geometry has registers to spare (ROOMY: two waves per SIMD, the frame loop over the
+    // work lists, where a basis change is 2.6 us = nine frames of a chain): then two rows per trip, two trips in flight
+    constexpr int R = (CPL == 1 && !ROOMY) ? 1 : 2;
+    constexpr int kTrips = ROOMY ? NP / 2 : 1; // (ROOMY: the whole product unrolled, so that the LDS reads of the matrix run ahead of the FMAs)
+#pragma unroll kTrips
     for (int i = 0; i < NP; i += R) {
         double a[R][CPL], a2[R][CPL]; // even / odd k: two dependent chains per output instead of one
 #pragma unroll
@@ -579,11 +581,14 @@ __device__ __forceinline__ void logl_body(const KParams &p)
         // modal basis change (X = R).  `after_left` runs on the mean columns between the
         // two multiplies (adds G in the dense predict).
         auto sandwich = [&](auto X, auto &&after_left) {
-            matvec_to_lds<NP, CPL>(X, col, scratch, cidx, hasImg);
+            matvec_to_lds<NP, CPL, (JUMP && ROW && OCC <= 2)>(X, col, scratch, cidx, hasImg);
             wave_lds_fence();
 #pragma unroll
             for (int q = 0; q < CPL; ++q) {
                 // covariance: walk row c of the image; mean: own column; spare: anything in range
+                // (tried: storing the covariance block ACROSS the image, so that this transposed read becomes five 16-byte
+                // reads and one wait instead of ten 8-byte reads each waited for -- the basis change gained 0.1 us and the
+                // frame loop, re-allocated by the compiler, lost 0.04 us per frame: 53.7 -> 56.9 us at k = 4; dropped)
                 const int c = isC[q] ? cidx[q] : (hasImg[q] ? cidx[q] * NP : 0);
                 const int st = isC[q] ? NP : 1;
                 const double keep = hasImg[q] ? 1.0 : 0.0;
@@ -592,7 +597,7 @@ __device__ __forceinline__ void logl_body(const KParams &p)
             }
             wave_lds_fence();
             after_left();
-            matvec_to_lds<NP, CPL>(X, col, scratch, cidx, isC);
+            matvec_to_lds<NP, CPL, (JUMP && ROW && OCC <= 2)>(X, col, scratch, cidx, isC);
             wave_lds_fence();
 #pragma unroll
             for (int q = 0; q < CPL; ++q)
@@ -629,7 +634,9 @@ __device__ __forceinline__ void logl_body(const KParams &p)
                         const int steps = p.tab_factored ? 2 : 1;
                         for (int st = 0; st < steps; ++st) {
                             const int slot = p.tab_factored ? (st == 0 ? s : S + sn) : sn * S + s;
+#ifndef BILD_EXPERIMENT_NO_SANDWICH // timing experiment only (wrong results): what the basis change itself costs
                             sandwich(const_cast<const double *>(smem) + (size_t)slot * MS, [] {});
+#endif
                         }
                     }
                     s = sn;
