@@ -939,7 +939,11 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
                                ts.trans_state == 1;
         // (the first geometry of the chain length: fewest tasks per wave, and the one whose LDS leaves room for the walk plan)
         const int64_t tasks_for_geometry = may_split ? 1 : n * ts.dstar_max;
-        if (!geometry_for(m.NPm[mode], mode, tasks_for_geometry, ts.means_max, &geom))
+        // (the frame loop over the work lists is latency-bound: the row layout -- three mean slots, the shortest frame for a lone
+        // wave -- also where fewer mean vectors would allow more tasks per wave; all geometries of a chain length agree bit for bit)
+        const int means_for_geometry = may_split ? std::max(ts.means_max, (int)kDMax) : ts.means_max;
+        if (!geometry_for(m.NPm[mode], mode, tasks_for_geometry, means_for_geometry, &geom) &&
+            !geometry_for(m.NPm[mode], mode, tasks_for_geometry, ts.means_max, &geom))
             return fail(BILD_ERR_UNSUPPORTED, "no kernel for %d rows", m.NPm[mode]);
         if (may_split) {
             Geometry lg{};
