@@ -38,87 +38,108 @@ def sample(traj, model,
     Parameters and defaults are those of the reference.  Returns `SamplingResults` -- also on
     ``KeyboardInterrupt``, with whatever has been sampled so far.
     """
-    traj = make_trajectory(traj)
-    progress = _progress_bar(show_progress)
-
-    samplers = []
-    log = {'k': [], 'pk': [], 'KLD': [], 'I_la': []}
-    state = {'fresh': False}
-
-    def add_sample(k):
-        if samplers[k].step():   # an exhausted sampler does nothing
-            progress.update()
-            for key in log:
-                log[key].append(None)
-            log['k'][-1] = k
-            state['fresh'] = True
-
-    def add_sampler(k):
-        assert k == len(samplers)
-        samplers.append(FixedkSampler(traj, model, k=k, **sampler_kw))
-        for _ in range(init_runs):
-            add_sample(k)
-
-    def next_k():
-        k_new = len(samplers)
-        if not state['fresh']:
-            return k_new if len(log['k']) == 0 else log['k'][-1]
-
-        logE = np.array([s.evidences[-1][0] for s in samplers])
-        dlogE = np.array([s.evidences[-1][1] for s in samplers])
-        nsteps = np.array([np.inf if s.exhausted else len(s.samples) for s in samplers])
-        cs = ChoiceSampler(logE, dlogE ** 2, nsteps, dE, **choice_kw)
-        pk = cs.n0 / cs.samplesize
-
-        # look-ahead region = the last k_lookahead samplers.  While every sampler is still inside
-        # it, its importance is infinite: open the next k right away (if allowed).
-        if k_new < k_lookahead + 1 and k_new <= k_max:
-            choice, KLD, I_la = k_new, None, np.inf
-        else:
-            KLD = cs.KLD_moreSamples()
-            choice = int(np.argmax(KLD))
-            I_la = cs.KLD_omitK(np.arange(k_new - k_lookahead, k_new)) if k_new >= k_lookahead + 1 else np.inf
-            if I_la > KLD[choice] and k_new <= k_max:
-                choice = k_new
-
-        log['pk'][-1] = pk
-        log['KLD'][-1] = KLD
-        log['I_la'][-1] = I_la
-        state['fresh'] = False
-        return choice
-
-    k_next = 0
-    running = True
+    run = _AdaptiveRun(make_trajectory(traj), model, dE, init_runs, certainty_in_k, k_lookahead, k_max,
+                       dict(sampler_kw), dict(choice_kw), _progress_bar(show_progress))
     try:
-        while running:
-            if k_next < len(samplers):
-                add_sample(k_next)
-            elif k_next == len(samplers):
-                add_sampler(k_next)
-            else:  # pragma: no cover
-                raise RuntimeError("Trying to sample outside of existing range; this is a bug")
-
-            progressed = state['fresh']
-            k_next = next_k()
-
-            if k_next == len(samplers):
-                # a new k takes precedence over the certainty criterion.  (When no sampler has taken a single step
-                # yet -- every k so far was enumerated exhaustively or has k >= T, i.e. a trajectory of a few frames
-                # -- the reference keeps opening samplers without looking at k_max, forever; here k_max ends it.)
-                running = k_next <= k_max
-            elif not progressed and samplers[k_next].exhausted:
-                # nothing was sampled in this round and the next candidate cannot sample either: the reference
-                # would spin on it; there is nothing left to learn
-                running = False
-            else:
-                running = np.max(log['pk'][-1]) < certainty_in_k
-                if log['KLD'][-1] is not None:
-                    # no information left to gain when all relevant samplers are exhausted
-                    running = running and log['KLD'][-1][k_next] > 0
-        progress.close()
+        run.loop()
     except KeyboardInterrupt:  # pragma: no cover
         pass
-    return SamplingResults(traj, model, dE, samplers, log)
+    return SamplingResults(run.traj, model, dE, run.samplers, run.log_columns())
+
+
+class _AdaptiveRun:
+    """
+    The adaptive-k loop of `sample` as a small state machine.
+
+    State: the samplers opened so far (index = k), one log row per AMIS step that was really taken, and `target`, the k
+    the next round works on (``len(samplers)`` = open a new one).  A round is `work` (take the step(s)) followed by
+    `judge` (rate the evidence curve, annotate the newest row, pick the next target) and `goes_on` (the stop rules).  The
+    decisions are those of reference bild/core.py:130-227; the random numbers are consumed in the same order (one
+    `ChoiceSampler` per round that took a step), so a seeded run reproduces the reference's sequence of k.
+    """
+
+    def __init__(self, traj, model, dE, init_runs, certainty_in_k, k_lookahead, k_max, sampler_kw, choice_kw, progress):
+        self.traj, self.model, self.dE = traj, model, dE
+        self.init_runs, self.certainty, self.lookahead, self.k_max = init_runs, certainty_in_k, k_lookahead, k_max
+        self.sampler_kw, self.choice_kw, self.progress = sampler_kw, choice_kw, progress
+        self.samplers = []
+        self.rows = []          # {'k', 'pk', 'KLD', 'I_la'} per step taken; only the newest row of a round is annotated
+        self.target = 0
+
+    # -- bookkeeping -----------------------------------------------------------------------------------------------
+    def log_columns(self):
+        return {key: [row[key] for row in self.rows] for key in ('k', 'pk', 'KLD', 'I_la')}
+
+    def _step(self, k):
+        """ one AMIS step of sampler k; False when that sampler is exhausted (nothing happens then) """
+        if not self.samplers[k].step():
+            return False
+        self.progress.update()
+        self.rows.append({'k': k, 'pk': None, 'KLD': None, 'I_la': None})
+        return True
+
+    def work(self):
+        """ the round's sampling: a new sampler gets `init_runs` steps at once, an existing one a single step """
+        k = self.target
+        if k > len(self.samplers):  # pragma: no cover
+            raise RuntimeError("Trying to sample outside of existing range; this is a bug")
+        if k < len(self.samplers):
+            return self._step(k)
+        self.samplers.append(FixedkSampler(self.traj, self.model, k=k, **self.sampler_kw))
+        return any([self._step(k) for _ in range(self.init_runs)])
+
+    # -- decisions -------------------------------------------------------------------------------------------------
+    def judge(self):
+        """ rate the evidence curve after a round that took a step; annotates the newest row and sets the next target """
+        opened = len(self.samplers)
+        may_open = opened <= self.k_max
+        last = [s.evidences[-1] for s in self.samplers]
+        budget = [np.inf if s.exhausted else len(s.samples) for s in self.samplers]
+        cs = ChoiceSampler(np.array([ev[0] for ev in last]), np.array([ev[1] for ev in last]) ** 2, np.array(budget),
+                           self.dE, **self.choice_kw)
+        row = self.rows[-1]
+        row['pk'] = cs.n0 / cs.samplesize
+        if opened <= self.lookahead and may_open:
+            # every sampler still lies inside the look-ahead window: whatever is behind it matters infinitely much
+            row['I_la'] = np.inf
+            self.target = opened
+            return
+        gain = cs.KLD_moreSamples()
+        window = np.arange(opened - self.lookahead, opened)
+        row['KLD'] = gain
+        row['I_la'] = cs.KLD_omitK(window) if opened > self.lookahead else np.inf
+        refine = int(np.argmax(gain))
+        self.target = opened if (may_open and row['I_la'] > gain[refine]) else refine
+
+    def goes_on(self, stepped):
+        k = self.target
+        if k == len(self.samplers):
+            # a new k takes precedence over the certainty criterion.  (When no sampler has taken a single step
+            # yet -- every k so far was enumerated exhaustively or has k >= T, i.e. a trajectory of a few frames
+            # -- the reference keeps opening samplers without looking at k_max, forever; here k_max ends it.)
+            return k <= self.k_max
+        if not stepped and self.samplers[k].exhausted:
+            # nothing was sampled in this round and the next candidate cannot sample either: the reference
+            # would spin on it; there is nothing left to learn
+            return False
+        newest = self.rows[-1]
+        if np.max(newest['pk']) >= self.certainty:
+            return False
+        # no information left to gain when all relevant samplers are exhausted
+        return newest['KLD'] is None or newest['KLD'][k] > 0
+
+    def loop(self):
+        while True:
+            stepped = self.work()
+            if stepped:
+                self.judge()
+            elif not self.rows:
+                self.target = len(self.samplers)
+            else:
+                self.target = self.rows[-1]['k']
+            if not self.goes_on(stepped):
+                break
+        self.progress.close()
 
 
 def sample_many(trajs, model, **kwargs):

@@ -49,23 +49,32 @@ class Loopingprofile:
         except Exception:
             return False
 
+    def _run_starts(self):
+        """ frames at which a new run of equal states begins (frame 0 excluded) """
+        return np.flatnonzero(self.state[1:] != self.state[:-1]) + 1
+
     def count_switches(self):
-        return int(np.count_nonzero(self.state[1:] != self.state[:-1]))
+        return int(self._run_starts().size)
 
     def intervals(self):
-        """ list of (start, end, state); start/end are None at the profile's ends """
-        boundaries = [None] + (np.nonzero(np.diff(self.state))[0] + 1).tolist()
-        ivs = [(bl, br, self.state[br - 1]) for bl, br in zip(boundaries[:-1], boundaries[1:])]
-        ivs.append((boundaries[-1], None, self.state[-1]))
-        return ivs
+        """
+        Runs of equal state as (start, end, state) triples (reference bild/util.py:109-126); the open ends of the profile
+        are reported as None, so that ``profile.state[start:end]`` is the run.
+        """
+        cuts = self._run_starts().tolist()
+        lefts = [None] + cuts
+        rights = cuts + [None]
+        return [(lo, hi, self.state[-1 if hi is None else hi - 1]) for lo, hi in zip(lefts, rights)]
 
     def plottable(self):
-        ivs = self.intervals()
-        ivs[0] = (0, ivs[0][1], ivs[0][2])
-        ivs[-1] = (ivs[-1][0], len(self), ivs[-1][2])
-        ivs = np.asarray(ivs)
-        t = ivs[:, :2].flatten() - 1
-        y = np.stack([ivs[:, 2], ivs[:, 2]], axis=-1).flatten()
+        """
+        Staircase (t, y) for plotting against the frame axis (reference bild/util.py:128-141): every run contributes its two
+        end points, ``profile[t]`` being drawn between frames t-1 and t.
+        """
+        cuts = self._run_starts()
+        edges = np.concatenate(([0], cuts, [len(self)]))
+        t = np.repeat(edges, 2)[1:-1] - 1
+        y = np.repeat(self.state[edges[:-1]], 2)
         return t, y
 
 
