@@ -190,7 +190,10 @@ __device__ __forceinline__ void logl_body(const KParams &p)
     // block layout: a group is one 16-lane block of the f64 4x4x4 matrix instruction (lanes that share
     // bits 2-3), so that S = s2 + w.(Cw) is a block sum on the matrix pipe
     constexpr bool BLK = LAY == 1;
-    constexpr bool ROW = LAY == 2;
+    constexpr bool ROW = LAY == 2 || LAY == 3;
+    // row layout for the frame loop over the work lists ONLY (geometry 23): never builds a table, so the instantiation
+    // carries none of the builders' tests in its frame loop
+    constexpr bool kLean = LAY == 3;
     static_assert(LAY == 0 || (G == 16 && CPL == 1), "block / row layouts: 16 lanes per task, one column per lane");
     constexpr int MS = table_stride(NP); // LDS matrix stride
     constexpr int SB = StateBlock::size(NP);
@@ -618,10 +621,9 @@ __device__ __forceinline__ void logl_body(const KParams &p)
         constexpr int kJumpFirst = BILD_JUMP_FIRST; // first comparison this many frames behind a switch
         int t_check = 0; // frame index (frames < t_check are processed) at which the next convergence check is due
         int s_loaded = s; // state whose vectors (wq, L, sgd) are in registers
-        // one frame t >= 1: state bookkeeping, predict (pyx:206-241), masked update (pyx:244-248)
-        auto frame = [&](int t, const double (&xv)[CPL], double probe) {
-            if (ROW) s2_now = row_const[0];
-            if (t >= next_start) {
+        // frame t is the first of a new segment: state bookkeeping, and the basis change of a real switch
+        auto enter_segment = [&](int t) {
+            {
                 do {
                     ++seg;
                     next_start = (seg + 1 < nseg) ? seg_start_of(seg + 1) : INT_MAX;
@@ -645,6 +647,10 @@ __device__ __forceinline__ void logl_body(const KParams &p)
                     t_check = t + kJumpFirst;
                 }
             }
+        };
+        // one frame t >= 1: predict (pyx:206-241), masked update (pyx:244-248)
+        auto frame = [&](const double (&xv)[CPL], double probe) {
+            if (ROW) s2_now = row_const[0];
             if (MODE == kModal) {
 #pragma unroll
                 for (int q = 0; q < CPL; ++q)
@@ -714,7 +720,7 @@ __device__ __forceinline__ void logl_body(const KParams &p)
         constexpr double kJumpTol = 1.1368683772161603e-13; // 2^-43
         const bool restore = !DUMP && p.prefix != nullptr;
         const bool jumping = JUMP && restore && !p.no_jump;
-        const bool building_transients = jumping && (p.trans_dump != nullptr || p.trans2_dump != nullptr);
+        const bool building_transients = !kLean && jumping && (p.trans_dump != nullptr || p.trans2_dump != nullptr);
         const bool use_transients = jumping && p.trans != nullptr && !building_transients;
         auto record_of = [&](int st, int t) { return p.prefix + (td->prefix_rec0 + ((int64_t)e * S + st) * T + t) * REC; };
         auto record = [&](int t) { return record_of(s, t); };
@@ -761,7 +767,9 @@ __device__ __forceinline__ void logl_body(const KParams &p)
         int t = 1;
         int nrun = 0; // frames run: minus the first frame of the open run while it lasts, plus its last frame + 1 when it ends
         double extra = 0.0; // finished pieces: table differences, transient entries, own pieces that have ended
-        bool open_run = true; // the accumulators hold a piece that is not in `extra` yet
+        // the accumulators hold a piece that is not in `extra` yet (an int: a loop-carried bool of divergent lanes is a lane mask
+        // in scalar registers, merged at the bottom of EVERY frame)
+        int open_run = 1;
         double xc[CPL], xn[CPL], pc, pn;
         // start a run of own frames at frame t0 from the table's state in front of it; the trajectory pointers stand at
         // frame t_ptr (0 at the start of a task, t + 1 inside the frame loop)
@@ -786,7 +794,7 @@ __device__ __forceinline__ void logl_body(const KParams &p)
             fetch(xn, pn); // frame t0 (or the first padding row)
             nrun -= t0;
             t_check = t0 + 8; // (a switch at t0 sets its own; lists too long to be cleaned may hold boundaries that switch nothing)
-            open_run = true;
+            open_run = 1;
         };
         auto start_run = [&](int t0, bool cumulative, int t_ptr) { start_from(record(t0 - 1), t0, cumulative, t_ptr); };
         // A chain of close switches begins at the synchronised point in front of frame t (the start of segment seg + 1).  With
@@ -909,7 +917,7 @@ __device__ __forceinline__ void logl_body(const KParams &p)
         unsigned long long clock_c = clock_b;
 #endif
         if (jumping) {
-            open_run = false;
+            open_run = 0;
             t = next_start < 1 ? 1 : (next_start < T ? next_start : T); // first switch (>= 1: segment 0 owns frame 0), or T
             if (!building_transients) {
                 extra = planned ? (double)walk[0] : record(t - 1)[kRecL];
@@ -952,7 +960,7 @@ __device__ __forceinline__ void logl_body(const KParams &p)
         };
         // this launch builds the transient table and, beside it, the transient state table (common.h): the state after
         // every frame of the transient goes to its record (tasks have two segments: the switch is at sst[1])
-        const bool dump_states = JUMP && building_transients && p.strans_dump != nullptr && K1 == 2 && nseg == 2;
+        const bool dump_states = JUMP && !kLean && building_transients && p.strans_dump != nullptr && K1 == 2 && nseg == 2;
         const int t_switch = dump_states ? seg_start_of(1) : 0;
         const int64_t state_rec0 = dump_states ? (td->strans0 + (((int64_t)e * S + seg_state_of(0)) * (S - 1) +
                                                                  (seg_state_of(1) - (seg_state_of(1) > seg_state_of(0) ? 1 : 0))) * T + t_switch) * p.sgap
@@ -975,13 +983,94 @@ __device__ __forceinline__ void logl_body(const KParams &p)
             }
         };
         if constexpr (DUMP) dump(0);
+        // The frame loop.  Per frame there is ONE test for everything that is not a frame: `t_event` is the next frame at which
+        // a segment begins or a comparison with the table is due.  (A lone wave issues an instruction every four cycles, a
+        // double-precision one every eight, whatever it is: the masks and branches of two separate tests -- a third in the
+        // instantiations that build tables -- were a tenth of a frame.)
+        auto next_event = [&]() {
+            const int tc = (JUMP && jumping && t_check > t) ? t_check : INT_MAX;
+            return next_start < tc ? next_start : tc;
+        };
+        int t_event = next_event();
         while (t < T) {
-            // invariant: xn holds frame t, the pointers stand at frame t + 1
+            // invariant: xn holds frame t, the pointers stand at frame t + 1.  The next frame's data are asked for FIRST, in
+            // front of the branch: in one basic block with the frame the scheduler sinks the load behind the last use of the
+            // current frame's data (same register), and the delivery below then waits for L2 in every frame
 #pragma unroll
             for (int q = 0; q < CPL; ++q) xc[q] = xn[q];
             pc = pn;
             fetch(xn, pn);
-            frame(t, xc, pc);
+            if (t >= t_event) {
+                if constexpr (JUMP) {
+                    if (jumping && t == t_check) { // the state after frame t - 1 against the table's
+#if defined(BILD_TASK_CLOCK) && BILD_TASK_CLOCK == 2
+                        const unsigned long long ev0 = wall_clock64();
+#endif
+                        const double *__restrict__ rec = record(t - 1);
+                        // per lane: largest deviation of the own column(s) from the table's, in units of the tolerance
+                        double excess = 0.0;
+                        bool same = true;
+#pragma unroll
+                        for (int q = 0; q < CPL; ++q) {
+                            if (!hasImg[q]) continue;
+                            // (mean columns: the floor is the scale of the DATA as far as the model can explain it -- for data drawn
+                            // from the model the largest coordinate itself, 4-5 standard deviations of the innovation; for data the model
+                            // did not produce (an offset, outliers) the innovations e grow with the data, the log-likelihood error of a
+                            // deviation d is ~ 20 |e| d / S, and the floor must not grow with them: TrajDesc::mscale)
+                            double dev = 0.0, ref = isM[q] ? td->mscale[e] : 0.0;
+#pragma unroll
+                            for (int i = 0; i < NP; i += 2) {
+                                const double2 r2 = *reinterpret_cast<const double2 *>(rec + cidx[q] * NP + i);
+                                dev = fmax(dev, fmax(fabs(col.v[q][i] - r2.x), fabs(col.v[q][i + 1] - r2.y)));
+                                ref = fmax(ref, fmax(fabs(r2.x), fabs(r2.y)));
+                            }
+                            const double bar = kJumpTol * ref;
+                            same = same && (dev <= bar); // a NaN anywhere never compares equal
+                            excess = fmax(excess, dev > bar ? dev / fmax(bar, 1e-300) : 0.0);
+                        }
+                        const unsigned long long agree = __ballot(same);
+                        if ((agree & group_mask) != group_mask) {
+                            // not yet: the deviation shrinks geometrically (the default Rouse model: 0.73 bits per frame), so the
+                            // next look comes after about the frames the worst column still needs at 1.3 frames per bit -- by the
+                            // lower edge of its bucket, i.e. rather too early than too late; a slower filter is simply asked again
+                            int wait = 4;
+                            if (__ballot(excess >= 0x1p4) & group_mask) wait = 8;
+                            if (__ballot(excess >= 0x1p8) & group_mask) wait = 12;
+                            if (__ballot(excess >= 0x1p16) & group_mask) wait = 24;
+                            if (__ballot(excess >= 0x1p24) & group_mask) wait = 32;
+                            if (__ballot(excess >= 0x1p32) & group_mask) wait = 44;
+                            if (__ballot(!(excess < 0x1p60)) & group_mask) wait = 64; // far off, or not a number
+                            t_check = t + wait;
+                        } else {
+                            // converged at frame t: the own piece ends here
+                            extra += piece_value();
+                            open_run = 0;
+                            nrun += t;
+                            if (building_transients) break;
+                            const int t_ptr = t + 2; // (frame t + 1 has been asked for)
+                            const int t2 = next_start < T ? next_start : T;
+                            extra += record(t2 - 1)[kRecL] - rec[kRecL];
+                            t = t2;
+                            land();
+                            if (t < T) {
+                                begin_chain(t_ptr); // leaves frame t in xn
+#pragma unroll
+                                for (int q = 0; q < CPL; ++q) xc[q] = xn[q];
+                                pc = pn;
+                                fetch(xn, pn);
+                            }
+                        }
+#if defined(BILD_TASK_CLOCK) && BILD_TASK_CLOCK == 2
+                        clock_events += wall_clock64() - ev0;
+                        ++n_events;
+#endif
+                        if (t >= T) break;
+                    }
+                }
+                if (t >= next_start) enter_segment(t);
+                t_event = next_event();
+            }
+            frame(xc, pc);
             if constexpr (DUMP) dump(t);
             ++t;
             if constexpr (JUMP) {
@@ -991,68 +1080,11 @@ __device__ __forceinline__ void logl_body(const KParams &p)
 #pragma unroll
                 for (int q = 0; q < CPL; ++q) asm volatile("" : "+v"(xn[q]));
             }
-            if constexpr (JUMP) {
+            if constexpr (JUMP && !kLean) {
                 if (dump_states && t < T && t - t_switch < p.sgap) dump_state(t - t_switch);
             }
-            if (JUMP && jumping && t == t_check && t < T) {
-#if defined(BILD_TASK_CLOCK) && BILD_TASK_CLOCK == 2
-                const unsigned long long ev0 = wall_clock64();
-#endif
-                const double *__restrict__ rec = record(t - 1);
-                // per lane: largest deviation of the own column(s) from the table's, in units of the tolerance
-                double excess = 0.0;
-                bool same = true;
-#pragma unroll
-                for (int q = 0; q < CPL; ++q) {
-                    if (!hasImg[q]) continue;
-                    // (mean columns: the floor is the scale of the DATA as far as the model can explain it -- for data drawn
-                    // from the model the largest coordinate itself, 4-5 standard deviations of the innovation; for data the model
-                    // did not produce (an offset, outliers) the innovations e grow with the data, the log-likelihood error of a
-                    // deviation d is ~ 20 |e| d / S, and the floor must not grow with them: TrajDesc::mscale)
-                    double dev = 0.0, ref = isM[q] ? td->mscale[e] : 0.0;
-#pragma unroll
-                    for (int i = 0; i < NP; i += 2) {
-                        const double2 r2 = *reinterpret_cast<const double2 *>(rec + cidx[q] * NP + i);
-                        dev = fmax(dev, fmax(fabs(col.v[q][i] - r2.x), fabs(col.v[q][i + 1] - r2.y)));
-                        ref = fmax(ref, fmax(fabs(r2.x), fabs(r2.y)));
-                    }
-                    const double bar = kJumpTol * ref;
-                    same = same && (dev <= bar); // a NaN anywhere never compares equal
-                    excess = fmax(excess, dev > bar ? dev / fmax(bar, 1e-300) : 0.0);
-                }
-                const unsigned long long agree = __ballot(same);
-                if ((agree & group_mask) != group_mask) {
-                    // not yet: the deviation shrinks geometrically (the default Rouse model: 0.73 bits per frame), so the
-                    // next look comes after about the frames the worst column still needs at 1.3 frames per bit -- by the
-                    // lower edge of its bucket, i.e. rather too early than too late; a slower filter is simply asked again
-                    int wait = 4;
-                    if (__ballot(excess >= 0x1p4) & group_mask) wait = 8;
-                    if (__ballot(excess >= 0x1p8) & group_mask) wait = 12;
-                    if (__ballot(excess >= 0x1p16) & group_mask) wait = 24;
-                    if (__ballot(excess >= 0x1p24) & group_mask) wait = 32;
-                    if (__ballot(excess >= 0x1p32) & group_mask) wait = 44;
-                    if (__ballot(!(excess < 0x1p60)) & group_mask) wait = 64; // far off, or not a number
-                    t_check = t + wait;
-                } else {
-                    // converged at frame t: the own piece ends here
-                    extra += piece_value();
-                    open_run = false;
-                    nrun += t;
-                    if (building_transients) break;
-                    const int t_ptr = t + 1;
-                    const int t2 = next_start < T ? next_start : T;
-                    extra += record(t2 - 1)[kRecL] - rec[kRecL];
-                    t = t2;
-                    land();
-                    if (t < T) begin_chain(t_ptr);
-                }
-#if defined(BILD_TASK_CLOCK) && BILD_TASK_CLOCK == 2
-                clock_events += wall_clock64() - ev0;
-                ++n_events;
-#endif
-            }
         }
-        if (open_run) {
+        if (open_run != 0) {
             extra += piece_value(); // a run that reached the end of the trajectory (all of it, without tables)
             nrun += t;
         }
@@ -1157,6 +1189,7 @@ int launch_geom(int mode, const KParams &p, int grid, size_t lds, hipStream_t st
     // (rouse.Model is built with F = 0, models.py:246): keep it out of the common kernels
     // (and trajectories without a single missing frame out of the masked ones)
     const int flavor = p.has_G ? 0 : (p.all_valid ? 2 : 1);
+    if (LAY == 3 && (p.prefix_dump || p.trans_dump || p.trans2_dump)) return (int)hipErrorInvalidValue; // (see kLean)
     if (p.prefix_dump) {
         // the table is built by the packed one-column geometry with room for kDMax mean vectors
         if constexpr (LAY == 0 && CPL == 1 && G == NP + kDMax) {
@@ -1219,7 +1252,7 @@ int launch_geom(int mode, const KParams &p, int grid, size_t lds, hipStream_t st
 //    run frame by frame three waves per SIMD stay the better geometry (r02_occ2_again.txt).
 //    (profiles/r02_row_layout.txt).  Listed before the packed geometry with the same number of tasks per wave, so the
 //    modal path picks it whenever three mean vectors are needed; with fewer, (1, 11) / (1, 12) carry 5 tasks per wave.
-// seventh field: layout (0 packed, 1 matrix-instruction block, 2 row); last field: which paths may select the geometry
+// seventh field: layout (0 packed, 1 matrix-instruction block, 2 row, 3 row for the frame loop over the work lists only); last field: which paths may select the geometry
 // automatically (1 = dense, 2 = modal, 3 = both).
 // The dense recursion is FMA-bound with one LDS operand feeding 2*CPL FMAs, so it wants several
 // columns per lane where the modal one wants a single column.
@@ -1235,7 +1268,7 @@ int launch_geom(int mode, const KParams &p, int grid, size_t lds, hipStream_t st
     X(19, 10, 1, 11, 4, 3, 0, 3)  \
     X(20, 10, 1, 12, 4, 3, 0, 3)  \
     X(21, 10, 1, 16, 4, BILD_ROW_OCC, 2, 2)  \
-    X(23, 10, 1, 16, 4, 2, 2, 0)  \
+    X(23, 10, 1, 16, 4, 2, 3, 0)  \
     X(3, 10, 1, 13, 4, 3, 0, 3)   \
     X(4, 10, 2, 7, 4, 2, 0, 3)    \
     X(22, 12, 1, 16, 4, 2, 2, 2)  \
