@@ -37,6 +37,7 @@
 // * sum_t log S_t is accumulated as a running product with exponent extraction
 //   (frexp) and one log per task, instead of one log per frame.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <hip/hip_ext.h>
 #include <limits.h>
 #include <math.h>
@@ -650,7 +651,7 @@ __device__ __forceinline__ void logl_body(const KParams &p)
         };
         // one frame t >= 1: predict (pyx:206-241), masked update (pyx:244-248)
         auto frame = [&](const double (&xv)[CPL], double probe) {
-            if (ROW) s2_now = row_const[0];
+            if (ROW && kLean) s2_now = row_const[0];
             if (MODE == kModal) {
 #pragma unroll
                 for (int q = 0; q < CPL; ++q)
@@ -767,9 +768,9 @@ __device__ __forceinline__ void logl_body(const KParams &p)
         int t = 1;
         int nrun = 0; // frames run: minus the first frame of the open run while it lasts, plus its last frame + 1 when it ends
         double extra = 0.0; // finished pieces: table differences, transient entries, own pieces that have ended
-        // the accumulators hold a piece that is not in `extra` yet (an int: a loop-carried bool of divergent lanes is a lane mask
-        // in scalar registers, merged at the bottom of EVERY frame)
-        int open_run = 1;
+        // the accumulators hold a piece that is not in `extra` yet (lean: an int -- a loop-carried bool of divergent lanes is a lane
+        // mask in scalar registers, merged at the bottom of EVERY frame)
+        typename std::conditional<kLean, int, bool>::type open_run = 1;
         double xc[CPL], xn[CPL], pc, pn;
         // start a run of own frames at frame t0 from the table's state in front of it; the trajectory pointers stand at
         // frame t_ptr (0 at the start of a task, t + 1 inside the frame loop)
@@ -983,105 +984,134 @@ __device__ __forceinline__ void logl_body(const KParams &p)
             }
         };
         if constexpr (DUMP) dump(0);
-        // The frame loop.  Per frame there is ONE test for everything that is not a frame: `t_event` is the next frame at which
-        // a segment begins or a comparison with the table is due.  (A lone wave issues an instruction every four cycles, a
-        // double-precision one every eight, whatever it is: the masks and branches of two separate tests -- a third in the
-        // instantiations that build tables -- were a tenth of a frame.)
-        auto next_event = [&]() {
-            const int tc = (JUMP && jumping && t_check > t) ? t_check : INT_MAX;
-            return next_start < tc ? next_start : tc;
-        };
-        int t_event = next_event();
-        while (t < T) {
-            // invariant: xn holds frame t, the pointers stand at frame t + 1.  The next frame's data are asked for FIRST, in
-            // front of the branch: in one basic block with the frame the scheduler sinks the load behind the last use of the
-            // current frame's data (same register), and the delivery below then waits for L2 in every frame
-#pragma unroll
-            for (int q = 0; q < CPL; ++q) xc[q] = xn[q];
-            pc = pn;
-            fetch(xn, pn);
-            if (t >= t_event) {
-                if constexpr (JUMP) {
-                    if (jumping && t == t_check) { // the state after frame t - 1 against the table's
+        // A comparison with the table is due at frame t (the state after frame t - 1 against the table's record): either the
+        // next look is scheduled, or the own piece ends here and the task goes on at its next synchronised point.
+        // Returns true when the task is finished with its frames (a table-building launch whose transient has converged).
+        auto compare_with_table = [&]() -> bool {
 #if defined(BILD_TASK_CLOCK) && BILD_TASK_CLOCK == 2
-                        const unsigned long long ev0 = wall_clock64();
+            const unsigned long long ev0 = wall_clock64();
 #endif
-                        const double *__restrict__ rec = record(t - 1);
-                        // per lane: largest deviation of the own column(s) from the table's, in units of the tolerance
-                        double excess = 0.0;
-                        bool same = true;
+            const double *__restrict__ rec = record(t - 1);
+            // per lane: largest deviation of the own column(s) from the table's, in units of the tolerance
+            double excess = 0.0;
+            bool same = true;
 #pragma unroll
-                        for (int q = 0; q < CPL; ++q) {
-                            if (!hasImg[q]) continue;
-                            // (mean columns: the floor is the scale of the DATA as far as the model can explain it -- for data drawn
-                            // from the model the largest coordinate itself, 4-5 standard deviations of the innovation; for data the model
-                            // did not produce (an offset, outliers) the innovations e grow with the data, the log-likelihood error of a
-                            // deviation d is ~ 20 |e| d / S, and the floor must not grow with them: TrajDesc::mscale)
-                            double dev = 0.0, ref = isM[q] ? td->mscale[e] : 0.0;
+            for (int q = 0; q < CPL; ++q) {
+                if (!hasImg[q]) continue;
+                // (mean columns: the floor is the scale of the DATA as far as the model can explain it -- for data drawn
+                // from the model the largest coordinate itself, 4-5 standard deviations of the innovation; for data the model
+                // did not produce (an offset, outliers) the innovations e grow with the data, the log-likelihood error of a
+                // deviation d is ~ 20 |e| d / S, and the floor must not grow with them: TrajDesc::mscale)
+                double dev = 0.0, ref = isM[q] ? td->mscale[e] : 0.0;
 #pragma unroll
-                            for (int i = 0; i < NP; i += 2) {
-                                const double2 r2 = *reinterpret_cast<const double2 *>(rec + cidx[q] * NP + i);
-                                dev = fmax(dev, fmax(fabs(col.v[q][i] - r2.x), fabs(col.v[q][i + 1] - r2.y)));
-                                ref = fmax(ref, fmax(fabs(r2.x), fabs(r2.y)));
-                            }
-                            const double bar = kJumpTol * ref;
-                            same = same && (dev <= bar); // a NaN anywhere never compares equal
-                            excess = fmax(excess, dev > bar ? dev / fmax(bar, 1e-300) : 0.0);
-                        }
-                        const unsigned long long agree = __ballot(same);
-                        if ((agree & group_mask) != group_mask) {
-                            // not yet: the deviation shrinks geometrically (the default Rouse model: 0.73 bits per frame), so the
-                            // next look comes after about the frames the worst column still needs at 1.3 frames per bit -- by the
-                            // lower edge of its bucket, i.e. rather too early than too late; a slower filter is simply asked again
-                            int wait = 4;
-                            if (__ballot(excess >= 0x1p4) & group_mask) wait = 8;
-                            if (__ballot(excess >= 0x1p8) & group_mask) wait = 12;
-                            if (__ballot(excess >= 0x1p16) & group_mask) wait = 24;
-                            if (__ballot(excess >= 0x1p24) & group_mask) wait = 32;
-                            if (__ballot(excess >= 0x1p32) & group_mask) wait = 44;
-                            if (__ballot(!(excess < 0x1p60)) & group_mask) wait = 64; // far off, or not a number
-                            t_check = t + wait;
-                        } else {
-                            // converged at frame t: the own piece ends here
-                            extra += piece_value();
-                            open_run = 0;
-                            nrun += t;
-                            if (building_transients) break;
-                            const int t_ptr = t + 2; // (frame t + 1 has been asked for)
-                            const int t2 = next_start < T ? next_start : T;
-                            extra += record(t2 - 1)[kRecL] - rec[kRecL];
-                            t = t2;
-                            land();
-                            if (t < T) {
-                                begin_chain(t_ptr); // leaves frame t in xn
+                for (int i = 0; i < NP; i += 2) {
+                    const double2 r2 = *reinterpret_cast<const double2 *>(rec + cidx[q] * NP + i);
+                    dev = fmax(dev, fmax(fabs(col.v[q][i] - r2.x), fabs(col.v[q][i + 1] - r2.y)));
+                    ref = fmax(ref, fmax(fabs(r2.x), fabs(r2.y)));
+                }
+                const double bar = kJumpTol * ref;
+                same = same && (dev <= bar); // a NaN anywhere never compares equal
+                excess = fmax(excess, dev > bar ? dev / fmax(bar, 1e-300) : 0.0);
+            }
+            const unsigned long long agree = __ballot(same);
+            if ((agree & group_mask) != group_mask) {
+                // not yet: the deviation shrinks geometrically (the default Rouse model: 0.73 bits per frame), so the
+                // next look comes after about the frames the worst column still needs at 1.3 frames per bit -- by the
+                // lower edge of its bucket, i.e. rather too early than too late; a slower filter is simply asked again
+                int wait = 4;
+                if (__ballot(excess >= 0x1p4) & group_mask) wait = 8;
+                if (__ballot(excess >= 0x1p8) & group_mask) wait = 12;
+                if (__ballot(excess >= 0x1p16) & group_mask) wait = 24;
+                if (__ballot(excess >= 0x1p24) & group_mask) wait = 32;
+                if (__ballot(excess >= 0x1p32) & group_mask) wait = 44;
+                if (__ballot(!(excess < 0x1p60)) & group_mask) wait = 64; // far off, or not a number
+                t_check = t + wait;
+            } else {
+                // converged at frame t: the own piece ends here
+                extra += piece_value();
+                open_run = 0;
+                nrun += t;
+                if (building_transients) return true;
+                // (the lean loop has asked for frame t + 1 already, the other one has not)
+                const int t_ptr = kLean ? t + 2 : t + 1;
+                const int t2 = next_start < T ? next_start : T;
+                extra += record(t2 - 1)[kRecL] - rec[kRecL];
+                t = t2;
+                land();
+                if (t < T) {
+                    begin_chain(t_ptr); // leaves frame t in xn
+                    if constexpr (kLean) {
 #pragma unroll
-                                for (int q = 0; q < CPL; ++q) xc[q] = xn[q];
-                                pc = pn;
-                                fetch(xn, pn);
-                            }
-                        }
-#if defined(BILD_TASK_CLOCK) && BILD_TASK_CLOCK == 2
-                        clock_events += wall_clock64() - ev0;
-                        ++n_events;
-#endif
-                        if (t >= T) break;
+                        for (int q = 0; q < CPL; ++q) xc[q] = xn[q];
+                        pc = pn;
+                        fetch(xn, pn);
                     }
                 }
-                if (t >= next_start) enter_segment(t);
-                t_event = next_event();
             }
-            frame(xc, pc);
-            if constexpr (DUMP) dump(t);
-            ++t;
-            if constexpr (JUMP) {
+#if defined(BILD_TASK_CLOCK) && BILD_TASK_CLOCK == 2
+            clock_events += wall_clock64() - ev0;
+            ++n_events;
+#endif
+            return false;
+        };
+        if constexpr (kLean) {
+            // The frame loop of the launch over the work lists.  A lone wave -- the chains that end a launch -- pays for every
+            // instruction around the frame: ONE test per frame for everything that is not a frame (`t_event`: the next frame at
+            // which a segment begins or a comparison is due), no tests of the table builders, no loop-carried flag in the scalar
+            // masks: 53 -> 48 us for the 10k x k = 4 launch, 97 -> 85 us at k = 8.  (The same structure costs the geometries that
+            // are short of registers more spills than it saves instructions -- (16, 1, 19) went from two reloads per frame to
+            // seven, 3x slower --, so they keep the loop below.)
+            auto next_event = [&]() {
+                const int tc = (jumping && t_check > t) ? t_check : INT_MAX;
+                return next_start < tc ? next_start : tc;
+            };
+            int t_event = next_event();
+            while (t < T) {
+                // invariant: xn holds frame t, the pointers stand at frame t + 1.  The next frame's data are asked for FIRST, in
+                // front of the branch: in one basic block with the frame the scheduler sinks the load behind the last use of the
+                // current frame's data (same register), and the delivery below then waits for L2 in every frame
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) xc[q] = xn[q];
+                pc = pn;
+                fetch(xn, pn);
+                if (t >= t_event) {
+                    if (jumping && t == t_check) {
+                        (void)compare_with_table();
+                        if (t >= T) break;
+                    }
+                    if (t >= next_start) enter_segment(t);
+                    t_event = next_event();
+                }
+                frame(xc, pc);
+                ++t;
                 // The next frame's data were asked for at the top of this one: take delivery HERE, a whole frame later, and
                 // not where the register allocator happens to copy them (mid-frame: a wave with the SIMD to itself -- the
                 // long chains that end a launch -- then waited for L2 in every frame: 0.45 us per frame instead of 0.24)
 #pragma unroll
                 for (int q = 0; q < CPL; ++q) asm volatile("" : "+v"(xn[q]));
             }
-            if constexpr (JUMP && !kLean) {
-                if (dump_states && t < T && t - t_switch < p.sgap) dump_state(t - t_switch);
+        } else {
+            while (t < T) {
+                // invariant: xn holds frame t, the pointers stand at frame t + 1
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) xc[q] = xn[q];
+                pc = pn;
+                fetch(xn, pn);
+                if (ROW) s2_now = row_const[0];
+                if (t >= next_start) enter_segment(t);
+                frame(xc, pc);
+                if constexpr (DUMP) dump(t);
+                ++t;
+                if constexpr (JUMP) {
+#pragma unroll
+                    for (int q = 0; q < CPL; ++q) asm volatile("" : "+v"(xn[q])); // (delivery of the next frame's data: see above)
+                }
+                if constexpr (JUMP) {
+                    if (dump_states && t < T && t - t_switch < p.sgap) dump_state(t - t_switch);
+                }
+                if (JUMP && jumping && t == t_check && t < T) {
+                    if (compare_with_table()) break;
+                }
             }
         }
         if (open_run != 0) {

@@ -10,10 +10,11 @@ import numpy as np, torch, helpers as H, bild_amd
 from bild_amd import _lib
 
 g = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 2   # states of the model; the candidates cycle through them
 T, n = 1000, 64
 rng = np.random.default_rng(2000)
-model = bild_amd.MultiStateRouse(20, 1., 5., d=3, localization_error=0.1)
-traj = model.trajectory_from_loopingprofile(H.random_profile(rng, T, 2, T // 5), rng=rng)
+model = bild_amd.MultiStateRouse(20, 1., 5., d=3, localization_error=0.1, **(dict(looppositions=H.LOOPS[S]) if S != 2 else {}))
+traj = model.trajectory_from_loopingprofile(H.random_profile(rng, T, S, T // 5), rng=rng)
 h, ts = model.handle(), model.trajset(traj)
 dev = torch.device('cuda', 0)
 rows = []
@@ -21,7 +22,7 @@ for K in (3, 5, 7, 9, 11, 13, 15):
     a = np.zeros((n, K + 1), dtype=np.int32)
     a[:, 1:] = 100 + g * np.arange(K)[None, :]
     b = np.zeros((n, K + 1), dtype=np.int32)
-    b[:, 1::2] = 1
+    b[:, :] = (np.arange(K + 1) % S)[None, :]
     da, db = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
     out = torch.zeros(n, dtype=torch.float64, device=dev)
     def go():
