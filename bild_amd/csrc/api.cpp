@@ -955,7 +955,9 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
     }
     // room for the walk plan (the table entries of all switches of a task, fetched at once) where it does not cost occupancy
     const size_t walk_bytes = fam == kVector ? (size_t)geom.W * (64 / geom.G) * kWalkDoubles * sizeof(double) : 0;
-    const bool walk_fits = fam == kVector && K1 <= kSegLds && lds + walk_bytes <= (size_t)48 * 1024 && !getenv("BILD_NO_WALK_PLAN");
+    // (a CU holds OCC waves per SIMD = 4 OCC / W workgroups of this geometry, and 160 KiB of LDS for them)
+    const size_t lds_per_workgroup = fam == kVector ? (size_t)160 * 1024 / (size_t)std::max(1, (4 * geom.OCC + geom.W - 1) / geom.W) : 0;
+    const bool walk_fits = fam == kVector && K1 <= kSegLds && lds + walk_bytes <= lds_per_workgroup && !getenv("BILD_NO_WALK_PLAN");
 
     bool timing; // this launch is bracketed by events (bild_kernel_timing: every p-th one) and counts the frames it runs
     {
