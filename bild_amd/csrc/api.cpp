@@ -935,8 +935,10 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
         // A split launch (below) sends only its chains of close switches through the frame loop -- a few per cent of a
         // batch with few switches per candidate, a third at k = 8 -- and deals them out itself, heaviest first.
         static const bool no_split_env0 = getenv("BILD_NO_SPLIT") != nullptr;
+        // (every condition of `split` below that is known here: a launch that takes the geometry of the listed frame loop and
+        // then runs the WHOLE batch with it would run at one or two waves per SIMD)
         const bool may_split = mode == kModal && K1 <= kSplitMaxK1 && !tl_building && !no_split_env0 && !(flags & (BILD_NO_SPLIT | BILD_NO_JUMP | BILD_NO_PREFIX)) &&
-                               ts.trans_state == 1;
+                               ts.trans_state == 1 && ts.d_prefix_L != nullptr && n * ts.dstar_max <= (int64_t)INT_MAX && !getenv("BILD_NO_WALK_PLAN");
         // (the first geometry of the chain length: fewest tasks per wave, and the one whose LDS leaves room for the walk plan)
         const int64_t tasks_for_geometry = may_split ? 1 : n * ts.dstar_max;
         // (the frame loop over the work lists is latency-bound: the row layout -- three mean slots, the shortest frame for a lone
@@ -947,7 +949,17 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
             return fail(BILD_ERR_UNSUPPORTED, "no kernel for %d rows", m.NPm[mode]);
         if (may_split) {
             Geometry lg{};
-            if (listed_geometry(geom, &lg)) geom = lg;
+            // (... including the room for the walk plan in the workgroup's share of the LDS)
+            if (listed_geometry(geom, &lg) &&
+                lds_bytes(m, lg, mode) + (size_t)lg.W * (64 / lg.G) * kWalkDoubles * sizeof(double) <= (size_t)160 * 1024 / (size_t)std::max(1, (4 * lg.OCC + lg.W - 1) / lg.W)) {
+                // A geometry at ONE wave per SIMD pays only while the list fits the chip once (it is latency-bound then); the
+                // list is written on the device, so its length is estimated: switches spread evenly over the trajectory, a
+                // candidate is listed when two neighbouring gaps are both shorter than a transient (10k x k = 4: 4 %, k = 8:
+                // a third).  A matter of speed only (configs[3]: k = 4 269 -> 297 M evals/s with it, k = 8 127 -> 97 M).
+                const double kk = K1 - 1, gap = 1.0 - std::exp(-(double)ts.trans_m_typ * (kk + 1) / (double)std::max(ts.Tmax, 1));
+                const double listed = (double)n * ts.dstar_max * std::min(1.0, 0.5 * std::max(kk - 1, 0.0) * gap * gap);
+                if (lg.OCC >= 2 || listed <= 1024.0 * lg.tasks_per_wave()) geom = lg;
+            }
         }
         lds = lds_bytes(m, geom, mode);
         if (lds > 160 * 1024)

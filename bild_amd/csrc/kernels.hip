@@ -1305,8 +1305,10 @@ int launch_geom(int mode, const KParams &p, int grid, size_t lds, hipStream_t st
     X(5, 12, 1, 15, 4, 2, 0, 3)   \
     X(6, 12, 2, 8, 4, 2, 0, 3)    \
     X(7, 16, 1, 19, 4, 2, 0, 2)   \
+    X(24, 16, 1, 19, 4, 1, 0, 0)  \
     X(8, 16, 3, 7, 4, 1, 0, 1)    \
     X(9, 20, 1, 23, 4, 2, 0, 2)   \
+    X(25, 20, 1, 23, 4, 1, 0, 0)  \
     X(10, 20, 2, 12, 4, 1, 0, 1)  \
     X(11, 20, 3, 8, 4, 1, 0, 1)   \
     X(12, 24, 1, 27, 4, 1, 0, 3)  \
@@ -1368,11 +1370,16 @@ bool geometry_for(int NP, int mode, int64_t ntasks, int means, Geometry *g)
     return true;
 }
 
+// The frame loop over the work lists is latency-bound (a few hundred tasks, the launch as long as its longest chain): it
+// takes the geometry of the chain length with the LARGEST register budget -- for 10 modes the row layout at two waves per SIMD
+// (id 23), for 16 / 20 modes the packed layout at one wave per SIMD (ids 24 / 25: what spills to scratch memory at two waves
+// per SIMD -- two reloads per frame, dozens per comparison -- stays in registers there).
 bool listed_geometry(const Geometry &from, Geometry *g)
 {
-    if (from.id != 21 || getenv("BILD_GEOM")) return false;
+    if (getenv("BILD_GEOM") || getenv("BILD_NO_LISTED_GEOMETRY")) return false;
+    const int to = from.id == 21 ? 23 : from.id == 7 ? 24 : from.id == 9 ? 25 : -1;
     for (const Geometry &c : kGeoms)
-        if (c.id == 23) {
+        if (c.id == to) {
             *g = c;
             return true;
         }
