@@ -194,8 +194,8 @@ __device__ __forceinline__ void logl_body(const KParams &p)
     constexpr bool ROW = LAY == 2 || LAY == 3;
     // row layout for the frame loop over the work lists ONLY (geometry 23): never builds a table, so the instantiation
     // carries none of the builders' tests in its frame loop
-    constexpr bool kLean = LAY == 3;
-    static_assert(LAY == 0 || (G == 16 && CPL == 1), "block / row layouts: 16 lanes per task, one column per lane");
+    constexpr bool kLean = LAY == 3 || LAY == 4; // (4: the packed layout, likewise for the listed launch only)
+    static_assert(LAY == 0 || LAY == 4 || (G == 16 && CPL == 1), "block / row layouts: 16 lanes per task, one column per lane");
     constexpr int MS = table_stride(NP); // LDS matrix stride
     constexpr int SB = StateBlock::size(NP);
     static_assert(NP % 2 == 0, "rows are read in pairs");
@@ -585,7 +585,7 @@ __device__ __forceinline__ void logl_body(const KParams &p)
         // modal basis change (X = R).  `after_left` runs on the mean columns between the
         // two multiplies (adds G in the dense predict).
         auto sandwich = [&](auto X, auto &&after_left) {
-            matvec_to_lds<NP, CPL, (JUMP && ROW && OCC <= 2)>(X, col, scratch, cidx, hasImg);
+            matvec_to_lds<NP, CPL, (JUMP && ((ROW && OCC <= 2) || kLean))>(X, col, scratch, cidx, hasImg);
             wave_lds_fence();
 #pragma unroll
             for (int q = 0; q < CPL; ++q) {
@@ -601,7 +601,7 @@ __device__ __forceinline__ void logl_body(const KParams &p)
             }
             wave_lds_fence();
             after_left();
-            matvec_to_lds<NP, CPL, (JUMP && ROW && OCC <= 2)>(X, col, scratch, cidx, isC);
+            matvec_to_lds<NP, CPL, (JUMP && ((ROW && OCC <= 2) || kLean))>(X, col, scratch, cidx, isC);
             wave_lds_fence();
 #pragma unroll
             for (int q = 0; q < CPL; ++q)
@@ -1219,7 +1219,7 @@ int launch_geom(int mode, const KParams &p, int grid, size_t lds, hipStream_t st
     // (rouse.Model is built with F = 0, models.py:246): keep it out of the common kernels
     // (and trajectories without a single missing frame out of the masked ones)
     const int flavor = p.has_G ? 0 : (p.all_valid ? 2 : 1);
-    if (LAY == 3 && (p.prefix_dump || p.trans_dump || p.trans2_dump)) return (int)hipErrorInvalidValue; // (see kLean)
+    if (LAY >= 3 && (p.prefix_dump || p.trans_dump || p.trans2_dump)) return (int)hipErrorInvalidValue; // (see kLean)
     if (p.prefix_dump) {
         // the table is built by the packed one-column geometry with room for kDMax mean vectors
         if constexpr (LAY == 0 && CPL == 1 && G == NP + kDMax) {
@@ -1282,7 +1282,7 @@ int launch_geom(int mode, const KParams &p, int grid, size_t lds, hipStream_t st
 //    run frame by frame three waves per SIMD stay the better geometry (r02_occ2_again.txt).
 //    (profiles/r02_row_layout.txt).  Listed before the packed geometry with the same number of tasks per wave, so the
 //    modal path picks it whenever three mean vectors are needed; with fewer, (1, 11) / (1, 12) carry 5 tasks per wave.
-// seventh field: layout (0 packed, 1 matrix-instruction block, 2 row, 3 row for the frame loop over the work lists only); last field: which paths may select the geometry
+// seventh field: layout (0 packed, 1 matrix-instruction block, 2 row; 3 / 4: row / packed for the frame loop over the work lists only); last field: which paths may select the geometry
 // automatically (1 = dense, 2 = modal, 3 = both).
 // The dense recursion is FMA-bound with one LDS operand feeding 2*CPL FMAs, so it wants several
 // columns per lane where the modal one wants a single column.
@@ -1305,10 +1305,10 @@ int launch_geom(int mode, const KParams &p, int grid, size_t lds, hipStream_t st
     X(5, 12, 1, 15, 4, 2, 0, 3)   \
     X(6, 12, 2, 8, 4, 2, 0, 3)    \
     X(7, 16, 1, 19, 4, 2, 0, 2)   \
-    X(24, 16, 1, 19, 4, 1, 0, 0)  \
+    X(24, 16, 1, 19, 4, 1, 4, 0)  \
     X(8, 16, 3, 7, 4, 1, 0, 1)    \
     X(9, 20, 1, 23, 4, 2, 0, 2)   \
-    X(25, 20, 1, 23, 4, 1, 0, 0)  \
+    X(25, 20, 1, 23, 4, 1, 4, 0)  \
     X(10, 20, 2, 12, 4, 1, 0, 1)  \
     X(11, 20, 3, 8, 4, 1, 0, 1)   \
     X(12, 24, 1, 27, 4, 1, 0, 3)  \
