@@ -847,7 +847,10 @@ int ensure_pairs(const bild_model &m, const bild_trajset &ts, hipStream_t st)
     ts.trans2_state = -1;
     if (ts.trans_state != 1 || getenv("BILD_NO_PAIRS") || m.S < 2) return BILD_OK;
     if (ts.expected_evals >= 0 && ts.expected_evals < kExpectPairs) return BILD_OK; // (the second-level tables pay from a few thousand evaluations on)
-    const int S = m.S, G = std::min(64, ts.trans_m_max);
+    // gaps the table covers: up to the longest converged transient of the single table, 128 at most (BILD_PAIRS_MAX_GAP: another cap --
+    // slow chains, whose transients last longer, leave more pairs to the frame loop)
+    static const int gap_cap = getenv("BILD_PAIRS_MAX_GAP") ? std::max(2, atoi(getenv("BILD_PAIRS_MAX_GAP"))) : 128;
+    const int S = m.S, G = std::min(gap_cap, ts.trans_m_max);
     if (G < 2) return BILD_OK;
     int64_t nb = 0;
     for (const TrajDesc &td : ts.descs) nb += (int64_t)std::max(td.T - 1, 0) * (G - 1) * S * (S - 1) * (S - 1);

@@ -1,7 +1,7 @@
 """
 Split launch (table walk + frame loop over the work lists, csrc/walk.hip) against the single launch (BILD_NO_SPLIT):
 device time of both kernels per number of switches, candidates resident in HBM, and the largest difference of the results
-(must be 0: same numbers added in the same order).    python tools/split_ab.py [n] [T] [k,k,...]
+(must be 0: same numbers added in the same order).    python tools/split_ab.py [n] [T] [k,k,...] [N]
 """
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,7 +13,8 @@ from bild_amd.profiles import segments_from_st
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 rng = np.random.default_rng(2000)
-model = bild_amd.MultiStateRouse(20, 1., 5., d=3, localization_error=0.1)
+N = int(sys.argv[4]) if len(sys.argv) > 4 else 20
+model = bild_amd.MultiStateRouse(N, 1., 5., d=3, localization_error=0.1)
 traj = model.trajectory_from_loopingprofile(H.random_profile(rng, T, 2, T // 5), rng=rng)
 h, ts = model.handle(), model.trajset(traj)
 dev = torch.device('cuda', 0)
