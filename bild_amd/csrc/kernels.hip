@@ -176,7 +176,8 @@ __device__ __forceinline__ void matvec_to_lds(XPtr X, const Cols<NP, CPL> &in, d
 // FLAVOR selects what the frame loop has to carry:
 //   0: external force (G != 0) and missing frames   1: missing frames   2: neither (every frame valid)
 // LAY: 0 packed groups of G consecutive lanes; 1 a group is a 16-lane block of the f64 4x4x4 matrix instruction
-// (S as a block sum on the matrix pipe); 2 a group is a 16-lane row, cross-lane operands by DPP row broadcast
+// (S as a block sum on the matrix pipe); 2 a group is a 16-lane row, cross-lane operands by DPP row broadcast;
+// 3 / 4: the row / the packed layout in the instantiation that serves the frame loop over the work lists only (kLean)
 // DUMP: this instantiation builds the prefix table (one per chain length is compiled, see launch_geom)
 // JUMP: this instantiation carries the machinery that takes frames out of the tables (convergence checks, transient table);
 // the frame-by-frame instantiation stays lean (the jump code costs registers the frame loop then spills around)
@@ -192,8 +193,8 @@ __device__ __forceinline__ void logl_body(const KParams &p)
     // bits 2-3), so that S = s2 + w.(Cw) is a block sum on the matrix pipe
     constexpr bool BLK = LAY == 1;
     constexpr bool ROW = LAY == 2 || LAY == 3;
-    // row layout for the frame loop over the work lists ONLY (geometry 23): never builds a table, so the instantiation
-    // carries none of the builders' tests in its frame loop
+    // the frame loop over the work lists ONLY (geometries 23 / 24 / 25): never builds a table, so the instantiation carries none
+    // of the builders' tests in its frame loop, and has a frame loop of its own (below)
     constexpr bool kLean = LAY == 3 || LAY == 4; // (4: the packed layout, likewise for the listed launch only)
     static_assert(LAY == 0 || LAY == 4 || (G == 16 && CPL == 1), "block / row layouts: 16 lanes per task, one column per lane");
     constexpr int MS = table_stride(NP); // LDS matrix stride
