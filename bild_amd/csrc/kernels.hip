@@ -47,6 +47,9 @@
 
 // expected frames of a wave's busiest row from which it asks for issue priority 1 / 2 / 3 (logl_kernel, "wave priority")
 #ifndef BILD_PRIO_T1
+#ifndef BILD_SNAKE
+#define BILD_SNAKE 1 // (0: every layer of a spread work list in the same direction -- A/B builds)
+#endif
 #define BILD_PRIO_T1 100
 #define BILD_PRIO_T2 130
 #define BILD_PRIO_T3 160
@@ -267,8 +270,11 @@ __device__ __forceinline__ void logl_body(const KParams &p)
     const int K1 = p.K1;
     const int64_t gstride = (int64_t)gridDim.x * (kWaves * GPW);
     const int64_t n_waves = (int64_t)gridDim.x * kWaves, wave_id = (int64_t)blockIdx.x * kWaves + wv;
-    // (listed, and the list fits the rows of the grid: spread -- row j of wave w takes slot j * n_waves + w)
-    const int64_t first_task = (listed && n_tasks <= gstride) ? (int64_t)grp * n_waves + wave_id : wave_id * GPW + grp;
+    // (listed, and the list fits the rows of the grid: spread -- row j of wave w takes slot j * n_waves + w, every second
+    // layer in reverse: the waves that carry the heaviest tasks of one layer get the lightest of the next, or none)
+    const int64_t first_task = (listed && n_tasks <= gstride)
+                                   ? (int64_t)grp * n_waves + (BILD_SNAKE && (grp & 1) ? n_waves - 1 - wave_id : wave_id)
+                                   : wave_id * GPW + grp;
 
     for (int64_t task = first_task; task < n_tasks; task += gstride) {
         int64_t r, otask;
