@@ -50,6 +50,9 @@
 #ifndef BILD_SNAKE
 #define BILD_SNAKE 1 // (0: every layer of a spread work list in the same direction -- A/B builds)
 #endif
+#ifndef BILD_SPREAD_ALWAYS
+#define BILD_SPREAD_ALWAYS 1 // (0: work lists longer than the grid has rows are packed, neighbouring slots to one wave)
+#endif
 #define BILD_PRIO_T1 100
 #define BILD_PRIO_T2 130
 #define BILD_PRIO_T3 160
@@ -272,11 +275,17 @@ __device__ __forceinline__ void logl_body(const KParams &p)
     const int64_t n_waves = (int64_t)gridDim.x * kWaves, wave_id = (int64_t)blockIdx.x * kWaves + wv;
     // (listed, and the list fits the rows of the grid: spread -- row j of wave w takes slot j * n_waves + w, every second
     // layer in reverse: the waves that carry the heaviest tasks of one layer get the lightest of the next, or none)
-    const int64_t first_task = (listed && n_tasks <= gstride)
-                                   ? (int64_t)grp * n_waves + (BILD_SNAKE && (grp & 1) ? n_waves - 1 - wave_id : wave_id)
-                                   : wave_id * GPW + grp;
+    const bool spread = listed && (BILD_SPREAD_ALWAYS || n_tasks <= gstride);
 
-    for (int64_t task = first_task; task < n_tasks; task += gstride) {
+    for (int64_t it = spread ? (int64_t)grp : wave_id * GPW + grp;; it += spread ? (int64_t)GPW : gstride) {
+        int64_t task = it;
+        if (spread) { // `it` counts layers of n_waves slots
+            if (it * n_waves >= n_tasks) break;
+            task = it * n_waves + (BILD_SNAKE && (it & 1) ? n_waves - 1 - wave_id : wave_id);
+            if (task >= n_tasks) continue;
+        } else if (task >= n_tasks) {
+            break;
+        }
         int64_t r, otask;
         int e;
         if (listed) {
