@@ -1293,21 +1293,23 @@ def test_declared_use_decides_which_tables_are_built(built_lib):
         assert np.max(np.abs(out[expect] - out[10])) < 1e-9
 
 
-@pytest.mark.parametrize('N,S,k', [(20, 3, 4), (20, 3, 8), (40, 2, 4)])
-def test_listed_frame_loop_of_longer_chains(built_lib, N, S, k):
+@pytest.mark.parametrize('N,S,k,n', [(20, 3, 4, 3000), (20, 3, 8, 3000), (40, 2, 4, 3000), (20, 3, 8, 30000), (20, 2, 12, 20000)])
+def test_listed_frame_loop_of_longer_chains(built_lib, N, S, k, n):
     """
     Chains of 16 and 20 modes (the 3-state model of BASELINE configs[3]; a 40-monomer 2-state chain): the frame loop over the
     work lists runs in a geometry of its own (one wave per SIMD, kernels.hip: listed_geometry) when the estimated list is
     short.  Same arithmetic: bit-identical to the single launch and to the launch in the batch geometry; < 1e-8 vs the oracle.
+    The two large cases have work lists of several layers and rounds (dealt out in snake order, three or four rows per wave):
+    every task must be run exactly once.
     """
     import os
     import bild_amd
     from bild_amd import _lib
     from bild_amd.profiles import segments_from_st
     rng = np.random.default_rng(500 + N + S + k)
-    T, n = 600, 3000
+    T = 600
     model = bild_amd.MultiStateRouse(N, 1, 5, d=3, looppositions=H.LOOPS[S], localization_error=0.1)
-    assert model.handle().query(_lib.Q_NP) in (16, 20)
+    assert model.handle().query(_lib.Q_NP) in (10, 16, 20)
     traj = model.trajectory_from_loopingprofile(H.random_profile(rng, T, S, 120), missing_frames=0.03, rng=rng)
     ss, th = H.candidate_profiles(rng, n, k, S)
     h, ts = model.handle(), model.trajset(traj)
