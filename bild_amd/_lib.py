@@ -39,8 +39,10 @@ class NoDeviceError(BildAmdError):
     pass
 
 
-_dp = ctypes.POINTER(ctypes.c_double)
-_ip = ctypes.POINTER(ctypes.c_int32)
+# (double* / int32* parameters are declared as addresses: a NumPy buffer is then passed as a plain integer -- dptr / iptr below --,
+# which costs a third of building a typed ctypes pointer per argument; byref(...) of an output scalar is accepted as before)
+_dp = ctypes.c_void_p
+_ip = ctypes.c_void_p
 _vp = ctypes.c_void_p
 
 _SIGNATURES = {
@@ -179,11 +181,18 @@ def i32(a):
 
 
 def dptr(a):
-    return a.ctypes.data_as(_dp)
+    """ address of a C-contiguous float64 array; the CALLER keeps the array alive across the call (no temporaries here) """
+    return a.__array_interface__['data'][0]
 
 
 def iptr(a):
-    return None if a is None else a.ctypes.data_as(_ip)
+    """ address of a C-contiguous int32 array, or None; lifetime as for `dptr` """
+    return None if a is None else a.__array_interface__['data'][0]
+
+
+def aptr(a):
+    """ address of a C-contiguous array of any element type (states as int64 / uint8, flags); lifetime as for `dptr` """
+    return a.__array_interface__['data'][0]
 
 
 class ModelHandle:
@@ -266,7 +275,7 @@ def logl_st(model, ts, ss, thetas, traj_id=None, path='auto', prefix=True, jump=
     assert ss.shape == (n, K1)
     tid = None if traj_id is None else i32(traj_id)
     out = np.empty(n, dtype=np.float64)
-    check(lib().bild_logl_st(model._h, ts._h, n, K1, dptr(ss), thetas.ctypes.data_as(_vp), iptr(tid), _flags(path, prefix=prefix, jump=jump, split=split), dptr(out)))
+    check(lib().bild_logl_st(model._h, ts._h, n, K1, dptr(ss), aptr(thetas), iptr(tid), _flags(path, prefix=prefix, jump=jump, split=split), dptr(out)))
     return out
 
 
@@ -277,7 +286,7 @@ def logl_st_to_device(model, ts, ss, thetas, d_out, traj_id=None, stream=0, path
     n, K1 = thetas.shape
     assert ss.shape == (n, K1)
     tid = None if traj_id is None else i32(traj_id)
-    check(lib().bild_logl_st_to_device(model._h, ts._h, n, K1, dptr(ss), thetas.ctypes.data_as(_vp), iptr(tid), PATHS[path],
+    check(lib().bild_logl_st_to_device(model._h, ts._h, n, K1, dptr(ss), aptr(thetas), iptr(tid), PATHS[path],
                                        _vp(stream) if stream else None, _vp(d_out)))
 
 
@@ -292,7 +301,7 @@ def segments_from_st(ss, thetas, T, n_states):
     seg_start = np.empty((n, K1), dtype=np.int32)
     seg_state = np.empty((n, K1), dtype=np.int32)
     check(lib().bild_segments_from_st(n, K1, int(n_states), iptr(Ts), 0 if len(Ts) == 1 else 1, dptr(ss),
-                                      thetas.ctypes.data_as(_vp), iptr(seg_start), iptr(seg_state)))
+                                      aptr(thetas), iptr(seg_start), iptr(seg_state)))
     return seg_start, seg_state
 
 
@@ -465,7 +474,7 @@ class DeviceBuffer:
 
     def to_host(self, n=None, stream=0):
         out = np.empty(self.n if n is None else int(n), dtype=np.float64)
-        check(lib().bild_device_to_host(out.ctypes.data_as(_vp), self._p, 8 * out.size, _vp(stream) if stream else None))
+        check(lib().bild_device_to_host(aptr(out), self._p, 8 * out.size, _vp(stream) if stream else None))
         return out
 
     def __del__(self):
@@ -486,11 +495,11 @@ class AmisCore:
         trans = np.ascontiguousarray(np.asarray(transitions) != 0, dtype=np.uint8)
         self.n = trans.shape[0]
         self.k1 = len(a0)
-        logp0 = f64(logp0)
+        logp0, a0 = f64(logp0), f64(a0)
         assert logp0.shape == (self.n, self.k1)
         self._h = _vp()
-        code = lib().bild_amis_create(self.k1, self.n, trans.ctypes.data_as(_vp), float(concentration_brake),
-                                      float(polarization_brake), float(logprior), dptr(f64(a0)), dptr(logp0),
+        code = lib().bild_amis_create(self.k1, self.n, aptr(trans), float(concentration_brake),
+                                      float(polarization_brake), float(logprior), dptr(a0), dptr(logp0),
                                       ctypes.byref(self._h))
         if code != OK:
             raise BildAmdError(code, "bild_amis_create failed")
@@ -526,7 +535,7 @@ class AmisCore:
         ss = f64(np.asarray(ss).reshape(-1, self.k1))
         thetas = np.ascontiguousarray(np.asarray(thetas).reshape(-1, self.k1), dtype=np.int64)
         cols = [f64(arrays[key]) for key in ('logLs', 'logδs', 'cur_log_proposal', 'log_weights')] if len(ss) else [f64([])] * 4
-        code = lib().bild_amis_restore(self._h, Q, dptr(a), dptr(logp), len(ss), dptr(ss), thetas.ctypes.data_as(_vp),
+        code = lib().bild_amis_restore(self._h, Q, dptr(a), dptr(logp), len(ss), dptr(ss), aptr(thetas),
                                        *(dptr(c) for c in cols))
         if code != OK:
             raise BildAmdError(code, "bild_amis_restore failed")
@@ -536,7 +545,7 @@ class AmisCore:
         u = f64(u)
         assert u.ndim == 2 and u.shape[0] == self.k1
         thetas = np.empty((u.shape[1], self.k1), dtype=np.int64)
-        code = lib().bild_amis_sample_traces(self._h, u.shape[1], dptr(u), thetas.ctypes.data_as(_vp))
+        code = lib().bild_amis_sample_traces(self._h, u.shape[1], dptr(u), aptr(thetas))
         if code != OK:
             raise BildAmdError(code, "bild_amis_sample_traces failed")
         return thetas
@@ -556,7 +565,7 @@ class AmisCore:
         thetas = np.ascontiguousarray(thetas, dtype=np.int64)
         assert ss.shape == thetas.shape == (len(logLs), self.k1)
         ev = np.empty(3)
-        code = lib().bild_amis_step(self._h, len(logLs), dptr(ss), thetas.ctypes.data_as(_vp), dptr(logLs), dptr(ev))
+        code = lib().bild_amis_step(self._h, len(logLs), dptr(ss), aptr(thetas), dptr(logLs), dptr(ev))
         if code != OK:
             msg = lib().bild_amis_error(self._h).decode()
             raise RuntimeError(msg) if 'converge' in msg else BildAmdError(code, msg)
@@ -572,7 +581,7 @@ def _amis_step_fused(self, model, ts, ss, thetas, path='auto'):
     thetas = np.ascontiguousarray(thetas, dtype=np.int64)
     assert ss.shape == thetas.shape and ss.shape[1] == self.k1
     ev = np.empty(3)
-    code = lib().bild_amis_step_fused(self._h, model._h, ts._h, len(ss), dptr(ss), thetas.ctypes.data_as(_vp), PATHS[path], dptr(ev))
+    code = lib().bild_amis_step_fused(self._h, model._h, ts._h, len(ss), dptr(ss), aptr(thetas), PATHS[path], dptr(ev))
     if code != OK:
         msg = lib().bild_amis_error(self._h).decode()
         raise RuntimeError(msg) if 'converge' in msg else BildAmdError(code, msg)
@@ -596,7 +605,7 @@ def _amis_pool_samples(self):
     """ (ss, thetas) of all pooled samples, fetched from the device where fused steps left them """
     P = len(self)
     ss, thetas = np.empty((P, self.k1)), np.empty((P, self.k1), dtype=np.int64)
-    if lib().bild_amis_pool_samples(self._h, dptr(ss), thetas.ctypes.data_as(_vp)) != OK:
+    if lib().bild_amis_pool_samples(self._h, dptr(ss), aptr(thetas)) != OK:
         raise BildAmdError(ERR_HIP, lib().bild_amis_error(self._h).decode())
     return ss, thetas
 
@@ -619,7 +628,7 @@ def choice_counts(rvs, mu, dmu, dE, omit=None, want_dn=True):
         flags = np.zeros(kmax, dtype=np.uint8)
         flags[omit] = 1
         n_omit = np.zeros(kmax, dtype=np.int64)
-    vp = lambda a: None if a is None else a.ctypes.data_as(_vp)
+    vp = lambda a: None if a is None else aptr(a)
     code = lib().bild_choice_counts(samplesize, kmax, dptr(rvs), dptr(mu), dptr(dmu), float(dE), vp(flags), vp(n0), vp(dn), vp(n_omit))
     if code != OK:
         raise BildAmdError(code, "bild_choice_counts failed")
