@@ -180,19 +180,27 @@ def i32(a):
     return np.ascontiguousarray(a, dtype=np.int32)
 
 
-def dptr(a):
-    """ address of a C-contiguous float64 array; the CALLER keeps the array alive across the call (no temporaries here) """
-    return a.__array_interface__['data'][0]
-
-
-def iptr(a):
-    """ address of a C-contiguous int32 array, or None; lifetime as for `dptr` """
-    return None if a is None else a.__array_interface__['data'][0]
+_addressof, _from_buffer = ctypes.addressof, ctypes.c_char.from_buffer
 
 
 def aptr(a):
-    """ address of a C-contiguous array of any element type (states as int64 / uint8, flags); lifetime as for `dptr` """
-    return a.__array_interface__['data'][0]
+    """
+    address of a C-contiguous array of any element type; the CALLER keeps the array alive across the call (no temporaries
+    here).  Through the buffer protocol where that works (0.4 us; writable, non-empty arrays), else through
+    ``__array_interface__`` (1.2 us; building a typed ctypes pointer costs 2.3).
+    """
+    try:
+        return _addressof(_from_buffer(a))
+    except (TypeError, ValueError, BufferError):
+        return a.__array_interface__['data'][0]
+
+
+dptr = aptr   # float64 buffers
+
+
+def iptr(a):
+    """ address of a C-contiguous int32 array, or None; lifetime as for `aptr` """
+    return None if a is None else aptr(a)
 
 
 class ModelHandle:

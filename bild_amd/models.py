@@ -227,7 +227,7 @@ class MultiStateRouse(MultiStateModel):
                 else as_array(t)
             arrs.append(a)
             noise = np.ascontiguousarray(self._get_noise(t), dtype=np.float64).tobytes()
-            addr = view.__array_interface__['data'][0] if isinstance(view, np.ndarray) else None
+            addr = _lib.aptr(view) if isinstance(view, np.ndarray) else None
             # `t[:]` of an ndarray or of this package's Trajectory is a view of one buffer; anything else is asked twice
             stable = addr is not None and (type(t) in (np.ndarray, Trajectory) or
                                            (isinstance(t[:], np.ndarray) and t[:].__array_interface__['data'][0] == addr))
@@ -237,7 +237,7 @@ class MultiStateRouse(MultiStateModel):
                 bits = a.reshape(-1).view(np.uint64)
                 if bits.size > 65536:
                     bits = bits[::bits.size // 65536 + 1]
-                out.append((addr, a.shape, noise, int(bits.sum())))
+                out.append((addr, a.shape, noise, int(np.add.reduce(bits))))
             else:   # no stable buffer to identify the data by: the contents are the key
                 out.append((None, a.shape, noise, hash(a.tobytes())))
         return out, arrs
