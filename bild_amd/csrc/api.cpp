@@ -1205,6 +1205,12 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
         (void)hipFreeAsync(target, st);
         if (lrc != 0) return fail(BILD_ERR_HIP, "reduce launch failed: %s", hipGetErrorString((hipError_t)lrc));
     }
+    if (st_in && !split) {
+        // every row went through the frame loop, the refused ones with a marked list of no switch: NaN for them, as in a split
+        // launch (entries that leave their results on the device cannot refuse a row otherwise)
+        lrc = launch_mark_refused_rows(d_seg_start, K1, n, d_out, (void *)st);
+        if (lrc != 0) return fail(BILD_ERR_HIP, "launch failed: %s", hipGetErrorString((hipError_t)lrc));
+    }
     return BILD_OK;
 }
 

@@ -169,6 +169,7 @@ struct WalkParams {
     int32_t debug;                  // timing experiments only (BILD_WALK_DEBUG; wrong results): 1 no pair loads, 2 no append, 4 no loads at all
 };
 int launch_walk(const WalkParams &p, void *stream, void *ev_start = nullptr, void *ev_stop = nullptr);
+int launch_mark_refused_rows(const int32_t *seg_start, int K1, int64_t n, double *out, void *stream);
 
 // launch geometry for a padded chain length
 struct Geometry {

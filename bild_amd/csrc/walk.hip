@@ -83,7 +83,19 @@ __device__ __forceinline__ int walk_task(const WalkParams &p, const int64_t task
         if (!ok) {
             // not a point on the simplex (or a state out of range): nothing of this row drives an address
             if (atomicCAS(p.status, 0, 1) == 0) p.status[1] = (int)(r < INT_MAX ? r : INT_MAX);
-            if (!p.convert_all) p.out[task] = __longlong_as_double(0x7ff8000000000000ll);
+            if (!p.convert_all) {
+                p.out[task] = __longlong_as_double(0x7ff8000000000000ll);
+            } else if (e == 0) {
+                // every list goes on to the frame loop: the refused row gets one without a switch (nothing of the row drives an
+                // address there either), marked by a negative first start -- a start no kernel reads, segment 0 owns frame 0 --,
+                // and its result is replaced by NaN behind the frame loop (mark_refused_rows_kernel)
+#pragma unroll
+                for (int i = 0; i < KMAX; ++i)
+                    if (i < K1) {
+                        p.seg_out_start[r * K1 + i] = i == 0 ? -1 : INT_MAX;
+                        p.seg_out_state[r * K1 + i] = 0;
+                    }
+            }
             return -1;
         }
     } else {
@@ -336,6 +348,24 @@ int launch_st(const WalkParams &p, hipStream_t st, hipEvent_t ev0, hipEvent_t ev
 }
 
 } // namespace
+
+namespace {
+__global__ void mark_refused_rows_kernel(const int32_t *__restrict__ seg_start, int K1, int64_t n, double *__restrict__ out)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n && seg_start[r * K1] < 0) out[r] = __longlong_as_double(0x7ff8000000000000ll);
+}
+} // namespace
+
+// (s, theta) rows whose lists were all converted for a single launch of the frame loop: NaN for the rows the conversion refused
+int launch_mark_refused_rows(const int32_t *seg_start, int K1, int64_t n, double *out, void *stream)
+{
+    if (n <= 0) return 0;
+    const int bs = 256;
+    hipLaunchKernelGGL(mark_refused_rows_kernel, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, reinterpret_cast<hipStream_t>(stream),
+                       seg_start, K1, n, out);
+    return (int)hipGetLastError();
+}
 
 int launch_walk(const WalkParams &p, void *stream, void *ev_start, void *ev_stop)
 {

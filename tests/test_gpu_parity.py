@@ -1325,3 +1325,42 @@ def test_listed_frame_loop_of_longer_chains(built_lib, N, S, k, n):
     assert np.array_equal(got, batch_geometry)
     a, b = segments_from_st(ss, th, T)
     assert _spot_check(model, [traj], a, b, np.zeros(n, np.int32), got, rng, 12, [T]) < TOL
+
+
+def test_refused_row_gets_nan_without_tables_too(built_lib):
+    """
+    Entries that leave their results on the device cannot refuse a row of (s, theta) that is no point on the simplex: it
+    gets NaN and the status word.  That must hold for the single launch as well -- a set that is not worth tables
+    (`expect`), the first evaluations on any set, BILD_NO_SPLIT -- where every list is converted and run: the refused row
+    runs a marked list without a switch and its result is replaced behind the frame loop.
+    """
+    import torch
+    import bild_amd
+    from bild_amd import _lib
+    rng = np.random.default_rng(4242)
+    T, n, k = 300, 500, 3
+    model = bild_amd.MultiStateRouse(20, 1, 5, d=3, localization_error=0.1)
+    traj = model.trajectory_from_loopingprofile(H.random_profile(rng, T, 2, 60), rng=rng)
+    h = model.handle()
+    ts = model.trajset(traj, expect=10)                      # a handful of evaluations: no tables, no split launch
+    ss, th = H.candidate_profiles(rng, n, k, 2)
+    want = _lib.logl_st(h, ts, ss, th)
+    assert _lib.prefix_info(ts)[0] == 0
+    bad = ss.copy()
+    bad[7, 1] = np.nan
+    bad[8, 0] = -0.25
+    dev = torch.device('cuda', 0)
+    d_ss = torch.from_numpy(bad).to(dev)
+    d_th = torch.from_numpy(th.astype(np.uint8)).to(dev)
+    out = torch.zeros(n, dtype=torch.float64, device=dev)
+    status = torch.zeros(2, dtype=torch.int32, device=dev)
+    _lib.logl_st_device(h, ts, n, k + 1, d_ss.data_ptr(), d_th.data_ptr(), out.data_ptr(), d_status=status.data_ptr())
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert np.isnan(got[7]) and np.isnan(got[8])
+    assert status.cpu().numpy()[0] == 1 and status.cpu().numpy()[1] in (7, 8)
+    keep = np.ones(n, dtype=bool)
+    keep[[7, 8]] = False
+    assert np.array_equal(got[keep], want[keep])
+    with pytest.raises(_lib.BildAmdError):
+        _lib.logl_st(h, ts, bad, th)                         # the host-buffer entry refuses the batch
