@@ -147,6 +147,8 @@ struct bild_amis {
         int64_t partial_host_cap = 0;
         void *stage = nullptr; // pinned host memory: the new samples of a step on their way up
         size_t stage_bytes = 0;
+        void *qstage = nullptr; // pinned host memory: the new proposal(s) of a step on their way up (fused step: asynchronous)
+        size_t qstage_bytes = 0;
     };
     int64_t log_ss_valid = 0; // samples whose log(s) the HOST holds (with the device mirror on, the device takes the logs)
     mutable Dev dev;
@@ -262,6 +264,7 @@ void dev_release(bild_amis::Dev &d)
     for (void *q : all)
         if (q) (void)hipFree(q);
     if (d.stage) (void)hipHostFree(d.stage);
+    if (d.qstage) (void)hipHostFree(d.qstage);
     if (d.partial_host) (void)hipHostFree(d.partial_host);
     d = bild_amis::Dev();
 }
@@ -303,7 +306,9 @@ int dev_reserve(bild_amis &m, int64_t P, int64_t Q)
 
 // upload what the host holds beyond the mirror: samples [d.P, P) (static data; with_state: also logd / cur / logw, for a
 // mirror that is switched on late) and proposals [d.Q, Q)
-int dev_push(bild_amis &m, bool with_state)
+// `stream` (fused step): the proposals go up asynchronously on the stream the passes run on, out of a pinned block of their own
+// -- four synchronous copies out of pageable memory were 50 us of every step; the step's last synchronisation covers them
+int dev_push(bild_amis &m, bool with_state, hipStream_t stream = nullptr, bool async_proposals = false)
 {
     bild_amis::Dev &d = m.dev;
     const size_t k1 = m.k1, k = m.k, n = m.n;
@@ -349,7 +354,30 @@ int dev_push(bild_amis &m, bool with_state)
         d.P = P;
     }
     const size_t qlo = (size_t)d.Q, qcnt = (size_t)(Q - d.Q);
-    if (qcnt) {
+    if (qcnt && async_proposals) {
+        struct Piece { const double *src; double *dst; size_t count; };
+        const Piece pieces[4] = {{m.a_flat.data() + qlo * k1, d.a + qlo * k1, qcnt * k1},
+                                 {m.dir_norm.data() + qlo, d.dir_norm + qlo, qcnt},
+                                 {m.head_flat.data() + qlo * n, d.head + qlo * n, qcnt * n},
+                                 {m.pair_flat.data() + qlo * k * n * n, d.pair + qlo * k * n * n, qcnt * k * n * n}};
+        size_t total = 0;
+        for (const Piece &pc : pieces) total += pc.count;
+        if (total * sizeof(double) > d.qstage_bytes) {
+            if (d.qstage) (void)hipHostFree(d.qstage);
+            d.qstage = nullptr;
+            d.qstage_bytes = 0;
+            AMIS_HIP(hipHostMalloc(&d.qstage, total * sizeof(double) * 2, hipHostMallocDefault));
+            d.qstage_bytes = total * sizeof(double) * 2;
+        }
+        double *q = (double *)d.qstage;
+        for (const Piece &pc : pieces) {
+            if (!pc.count) continue;
+            std::memcpy(q, pc.src, pc.count * sizeof(double));
+            AMIS_HIP(hipMemcpyAsync(pc.dst, q, pc.count * sizeof(double), hipMemcpyHostToDevice, stream));
+            q += pc.count;
+        }
+        d.Q = Q;
+    } else if (qcnt) {
         AMIS_HIP(hipMemcpy(d.a + qlo * k1, m.a_flat.data() + qlo * k1, qcnt * k1 * sizeof(double), hipMemcpyHostToDevice));
         AMIS_HIP(hipMemcpy(d.dir_norm + qlo, m.dir_norm.data() + qlo, qcnt * sizeof(double), hipMemcpyHostToDevice));
         AMIS_HIP(hipMemcpy(d.head + qlo * n, m.head_flat.data() + qlo * n, qcnt * n * sizeof(double), hipMemcpyHostToDevice));
@@ -669,7 +697,14 @@ static int amis_step_impl(bild_amis *m, int64_t N, const double *ss, const int64
     if (fused) {
         bild_amis::Dev &d = m->dev;
         int rc;
-        if ((rc = dev_push(*m, false))) return rc; // proposals not yet mirrored (and room for them)
+        // everything of this step goes to the model's own stream: the copies, the likelihood, the passes
+        void *stream = bild::internal_model_stream(model);
+        if (!stream) {
+            m->err = bild_last_error();
+            return BILD_ERR_HIP;
+        }
+        st = (hipStream_t)stream;
+        if ((rc = dev_push(*m, false, st, true))) return rc; // proposals not yet mirrored (and room for them)
         if ((rc = dev_reserve(*m, P, (int64_t)Q))) return rc;
         const size_t nseg = (size_t)N * k1;
         const size_t par_bytes = ((size_t)(k1 + n * k1) * sizeof(double) + (size_t)n * n + 15) & ~(size_t)15;
@@ -707,13 +742,6 @@ static int amis_step_impl(bild_amis *m, int64_t N, const double *ss, const int64
             for (size_t i = 0; i < nseg; ++i) t8[i] = (uint8_t)thetas[i]; // (range checked above)
         }
         lap("[amis step fused] stage");
-        // everything of this step goes to the model's own stream: the copies, the likelihood, the passes
-        void *stream = bild::internal_model_stream(model);
-        if (!stream) {
-            m->err = bild_last_error();
-            return BILD_ERR_HIP;
-        }
-        st = (hipStream_t)stream;
         if (draw) {
             const double *dp = d.draw_par;
             if (hipMemcpyAsync(d.draw_par, d.stage, par_bytes, hipMemcpyHostToDevice, st) != hipSuccess ||

@@ -1,0 +1,12 @@
+import os, sys, time
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), 'tests'))
+import numpy as np, helpers as H, bild_amd
+rng = np.random.default_rng(0)
+model = bild_amd.MultiStateRouse(20, 1, 5, d=3, localization_error=0.1)
+traj = model.trajectory_from_loopingprofile(H.random_profile(rng, 1000, 2, 200), rng=rng)
+np.random.seed(1)
+s = bild_amd.FixedkSampler(traj, model, k=4, N=10000, max_fev=10 ** 9, device_bookkeeping=True, fused=True, rng='device', seed=5)
+for _ in range(5): s.step()
+t0 = time.perf_counter()
+for _ in range(40): s.step()
+print("ms per step", (time.perf_counter() - t0) / 40 * 1e3)
