@@ -1,5 +1,9 @@
-import os, sys, time
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), 'tests'))
+#!/usr/bin/env python3
+""" the AMIS step with draws on the device (opt-in): time per step, the native stages (BILD_AMIS_TRACE=1) and a cProfile of the Python
+    side.     python tools/amis_rng_trace.py """
+import os, sys, time, cProfile, pstats
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, helpers as H, bild_amd
 rng = np.random.default_rng(0)
 model = bild_amd.MultiStateRouse(20, 1, 5, d=3, localization_error=0.1)
@@ -10,3 +14,8 @@ for _ in range(5): s.step()
 t0 = time.perf_counter()
 for _ in range(40): s.step()
 print("ms per step", (time.perf_counter() - t0) / 40 * 1e3)
+if not os.environ.get('BILD_AMIS_TRACE'):
+    pr = cProfile.Profile(); pr.enable()
+    for _ in range(40): s.step()
+    pr.disable()
+    pstats.Stats(pr).sort_stats('tottime').print_stats(10)
