@@ -140,11 +140,9 @@ struct bild_amis {
         uint8_t *has_zero = nullptr;
         int32_t *first = nullptr, *pcode = nullptr, *theta = nullptr;
         uint8_t *theta8 = nullptr; // fused step: the states as they went up for the likelihood (P x k1)
-        double *partial = nullptr, *mean = nullptr;
+        double *partial = nullptr, *mean = nullptr; // partial: PINNED HOST memory the passes write their block sums into
         int64_t partial_cap = 0;
         double *draw_par = nullptr;     // device-side draws: [a (k1) | slot weights (n x k1) | transitions (n x n bytes)]
-        double *partial_host = nullptr; // pinned: the partial sums of a pass on their way down
-        int64_t partial_host_cap = 0;
         void *stage = nullptr; // pinned host memory: the new samples of a step on their way up
         size_t stage_bytes = 0;
         void *qstage = nullptr; // pinned host memory: the new proposal(s) of a step on their way up (fused step: asynchronous)
@@ -260,12 +258,12 @@ int dev_regrow(bild_amis &m, T *&ptr, size_t old_count, size_t new_count)
 void dev_release(bild_amis::Dev &d)
 {
     void *all[] = {d.a, d.dir_norm, d.head, d.pair, d.ss, d.log_ss, d.logL, d.logd, d.cur, d.logw, d.rel, d.has_zero, d.first,
-                   d.pcode, d.theta, d.theta8, d.partial, d.mean, d.draw_par};
+                   d.pcode, d.theta, d.theta8, d.mean, d.draw_par};
     for (void *q : all)
         if (q) (void)hipFree(q);
     if (d.stage) (void)hipHostFree(d.stage);
     if (d.qstage) (void)hipHostFree(d.qstage);
-    if (d.partial_host) (void)hipHostFree(d.partial_host);
+    if (d.partial) (void)hipHostFree(d.partial);
     d = bild_amis::Dev();
 }
 
@@ -454,17 +452,11 @@ bild::AmisView dev_view(const bild_amis &m)
 // the partial sums of the pass just launched on `st`, through pinned memory; waits for the stream
 int dev_partials(bild_amis &m, int64_t doubles, std::vector<double> &host, hipStream_t st)
 {
+    // (the passes write their partial sums straight into pinned host memory -- a few tens of KB of posted writes per pass --:
+    // no copy command to enqueue and wait for between a pass and the host's sums)
     bild_amis::Dev &d = m.dev;
-    if (doubles > d.partial_host_cap) {
-        if (d.partial_host) (void)hipHostFree(d.partial_host);
-        d.partial_host = nullptr;
-        d.partial_host_cap = 0;
-        AMIS_HIP(hipHostMalloc((void **)&d.partial_host, (size_t)doubles * 2 * sizeof(double), hipHostMallocDefault));
-        d.partial_host_cap = doubles * 2;
-    }
-    AMIS_HIP(hipMemcpyAsync(d.partial_host, d.partial, (size_t)doubles * sizeof(double), hipMemcpyDeviceToHost, st));
     AMIS_HIP(hipStreamSynchronize(st));
-    host.assign(d.partial_host, d.partial_host + doubles);
+    host.assign(d.partial, d.partial + doubles);
     return BILD_OK;
 }
 
@@ -809,9 +801,9 @@ static int amis_step_impl(bild_amis *m, int64_t N, const double *ss, const int64
         const int rows_a = bild::amis_dev_pass_a_rows(P0, P);
         const int64_t need = std::max<int64_t>((int64_t)blocks * (2 + k1 + nm), (int64_t)rows_a * 2);
         if (need > m->dev.partial_cap) {
-            if (m->dev.partial) (void)hipFree(m->dev.partial);
+            if (m->dev.partial) (void)hipHostFree(m->dev.partial);
             m->dev.partial = nullptr;
-            if (hipMalloc((void **)&m->dev.partial, (size_t)need * 2 * sizeof(double)) != hipSuccess) {
+            if (hipHostMalloc((void **)&m->dev.partial, (size_t)need * 2 * sizeof(double), hipHostMallocDefault) != hipSuccess) {
                 m->err = "device bookkeeping: out of memory";
                 return BILD_ERR_HIP;
             }
