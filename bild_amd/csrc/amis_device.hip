@@ -42,7 +42,7 @@ struct AmisDerive {
 
 __global__ void __launch_bounds__(kAmisBlock) pass_a_kernel(AmisView v, int64_t Q, int64_t P0, int64_t lo, int64_t hi, int per_lane,
                                                             int row0, double logQ, double *log_ss, double *cur, double *logd,
-                                                            double *logw, double *partial, AmisDerive dv)
+                                                            double *logw, double *partial, AmisDerive dv, double *lq_keep)
 {
     __shared__ double top_s[kAmisBlock];
     __shared__ int nan_s;
@@ -76,8 +76,12 @@ __global__ void __launch_bounds__(kAmisBlock) pass_a_kernel(AmisView v, int64_t 
             double mx = amis_neg_inf();
             bool nan_q = false;
             cq = 0.0;
+            // (the log-densities are kept for the second loop -- lq_keep: Q rows of hi - lo values, neighbouring lanes next to
+            // each other -- instead of being computed twice: they are most of this kernel)
+            const int64_t n_new = hi - lo, col = p - lo;
             for (int64_t q = 0; q < Q; ++q) {
                 const double lq = amis_log_q(v, q, p);
+                if (lq_keep) lq_keep[q * n_new + col] = lq;
                 if (q == Q - 1) cq = lq;
                 nan_q |= lq != lq;
                 mx = lq > mx ? lq : mx;
@@ -87,7 +91,7 @@ __global__ void __launch_bounds__(kAmisBlock) pass_a_kernel(AmisView v, int64_t 
             } else {
                 if (!(mx > amis_neg_inf() && mx < -amis_neg_inf())) mx = 0.0;
                 double s = 0.0;
-                for (int64_t q = 0; q < Q; ++q) s += exp(amis_log_q(v, q, p) - mx);
+                for (int64_t q = 0; q < Q; ++q) s += exp((lq_keep ? lq_keep[q * n_new + col] : amis_log_q(v, q, p)) - mx);
                 ld = log(s) + mx;
             }
         }
@@ -319,20 +323,20 @@ int finish(hipStream_t st, bool wait)
 
 int amis_dev_pass_a(const AmisView &v, int64_t Q, int64_t P0, int64_t P, double logQ, double *log_ss, double *cur, double *logd,
                     double *logw, double *partial, int *rows, void *stream, const uint8_t *theta8, uint8_t *has_zero, int32_t *first,
-                    int32_t *pcode, int32_t *theta)
+                    int32_t *pcode, int32_t *theta, double *lq_keep)
 {
     hipStream_t st = (hipStream_t)stream;
     const AmisDerive dv{theta8, has_zero, first, pcode, theta};
-    // the samples drawn so far: one log-density each, kAmisPerLane per lane; the new ones: all Q proposals each (twice:
+    // the samples drawn so far: one log-density each, kAmisPerLaneA per lane; the new ones: all Q proposals each (twice:
     // maximum, then sum) -- one per lane, or ten blocks would work while the rest of the chip looks on
-    const int64_t per_block = (int64_t)kAmisBlock * kAmisPerLane;
+    const int64_t per_block = (int64_t)kAmisBlock * kAmisPerLaneA;
     const int old_blocks = (int)((P0 + per_block - 1) / per_block), new_blocks = (int)((P - P0 + kAmisBlock - 1) / kAmisBlock);
     if (old_blocks)
-        hipLaunchKernelGGL(pass_a_kernel, dim3(old_blocks), dim3(kAmisBlock), 0, st, v, Q, P0, (int64_t)0, P0, kAmisPerLane, 0, logQ,
-                           log_ss, cur, logd, logw, partial, dv);
+        hipLaunchKernelGGL(pass_a_kernel, dim3(old_blocks), dim3(kAmisBlock), 0, st, v, Q, P0, (int64_t)0, P0, kAmisPerLaneA, 0, logQ,
+                           log_ss, cur, logd, logw, partial, dv, (double *)nullptr);
     if (new_blocks)
         hipLaunchKernelGGL(pass_a_kernel, dim3(new_blocks), dim3(kAmisBlock), 0, st, v, Q, P0, P0, P, 1, old_blocks, logQ, log_ss,
-                           cur, logd, logw, partial, dv);
+                           cur, logd, logw, partial, dv, lq_keep);
     *rows = old_blocks + new_blocks;
     return finish(st, false);
 }
@@ -347,7 +351,7 @@ int amis_dev_draw(int k1, int n, int64_t N, uint64_t seed, uint64_t step, const 
 
 int amis_dev_pass_a_rows(int64_t P0, int64_t P)
 {
-    const int64_t per_block = (int64_t)kAmisBlock * kAmisPerLane;
+    const int64_t per_block = (int64_t)kAmisBlock * kAmisPerLaneA;
     return (int)((P0 + per_block - 1) / per_block) + (int)((P - P0 + kAmisBlock - 1) / kAmisBlock);
 }
 

@@ -140,6 +140,8 @@ struct bild_amis {
         uint8_t *has_zero = nullptr;
         int32_t *first = nullptr, *pcode = nullptr, *theta = nullptr;
         uint8_t *theta8 = nullptr; // fused step: the states as they went up for the likelihood (P x k1)
+        double *lq_keep = nullptr; // pass A: the new samples' log-densities under all proposals, between its two loops
+        int64_t lq_cap = 0;
         double *partial = nullptr, *mean = nullptr; // partial: PINNED HOST memory the passes write their block sums into
         int64_t partial_cap = 0;
         double *draw_par = nullptr;     // device-side draws: [a (k1) | slot weights (n x k1) | transitions (n x n bytes)]
@@ -258,7 +260,7 @@ int dev_regrow(bild_amis &m, T *&ptr, size_t old_count, size_t new_count)
 void dev_release(bild_amis::Dev &d)
 {
     void *all[] = {d.a, d.dir_norm, d.head, d.pair, d.ss, d.log_ss, d.logL, d.logd, d.cur, d.logw, d.rel, d.has_zero, d.first,
-                   d.pcode, d.theta, d.theta8, d.mean, d.draw_par};
+                   d.pcode, d.theta, d.theta8, d.mean, d.draw_par, d.lq_keep};
     for (void *q : all)
         if (q) (void)hipFree(q);
     if (d.stage) (void)hipHostFree(d.stage);
@@ -813,8 +815,15 @@ static int amis_step_impl(bild_amis *m, int64_t N, const double *ss, const int64
         std::vector<double> part;
         int rows = 0;
         bild_amis::Dev &d = m->dev;
+        if ((int64_t)Q * N > d.lq_cap) { // (scratch only: nothing to keep across a regrowth; without it the pass computes twice)
+            if (d.lq_keep) (void)hipFree(d.lq_keep);
+            d.lq_keep = nullptr;
+            d.lq_cap = 0;
+            if (hipMalloc((void **)&d.lq_keep, (size_t)Q * N * 2 * sizeof(double)) == hipSuccess) d.lq_cap = (int64_t)Q * N * 2;
+            else (void)hipGetLastError();
+        }
         if (bild::amis_dev_pass_a(dv, (int64_t)Q, P0, P, logQ, d.log_ss, d.cur, d.logd, d.logw, d.partial, &rows, (void *)st,
-                                  fused ? d.theta8 : nullptr, d.has_zero, d.first, d.pcode, d.theta)) {
+                                  fused ? d.theta8 : nullptr, d.has_zero, d.first, d.pcode, d.theta, d.lq_keep)) {
             m->err = "device bookkeeping: pass A failed";
             return BILD_ERR_HIP;
         }

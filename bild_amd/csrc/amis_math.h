@@ -86,7 +86,10 @@ BILD_HD inline double amis_rel_weight(double logw, double top)
 // `width` doubles per block.
 struct AmisDeviceOut; // host-side staging owned by amis_host.cpp
 constexpr int kAmisBlock = 64;        // lanes per block (one accumulator column in LDS per lane)
-constexpr int kAmisPerLane = 16;      // samples per lane
+constexpr int kAmisPerLane = 8;       // samples per lane (passes B and C: one row of partial sums per block comes down)
+constexpr int kAmisPerLaneA = 2;      // ... of pass A over the samples drawn so far: two numbers per block come down, and the pass is
+                                      // bound by what ONE lane does in sequence (a log-density with its exp / log1p per sample), not by
+                                      // the chip: 440 waves for 450 000 samples left most SIMDs idle
 constexpr int kAmisMaxNm = 64;        // n * k1 the device passes support
 int amis_dev_pass_a_rows(int64_t P0, int64_t P); // rows of `partial` pass A writes
 // N samples from the proposal (a: k1 concentrations; prob: n x k1 slot weights, normalised per slot; trans: n x n) drawn on
@@ -97,7 +100,8 @@ int amis_dev_draw(int k1, int n, int64_t N, uint64_t seed, uint64_t step, const 
 // theta: see AmisDerive in amis_device.hip -- null when the host has prepared the new samples)
 int amis_dev_pass_a(const AmisView &v, int64_t Q, int64_t P0, int64_t P, double logQ, double *log_ss /* = v.log_ss: written for the new samples */,
                     double *cur, double *logd, double *logw, double *partial /* rows x 2: max, any NaN */, int *rows, void *stream,
-                    const uint8_t *theta8, uint8_t *has_zero, int32_t *first, int32_t *pcode, int32_t *theta);
+                    const uint8_t *theta8, uint8_t *has_zero, int32_t *first, int32_t *pcode, int32_t *theta,
+                    double *lq_keep /* device, Q x (P - P0) doubles, or null: scratch for the new samples' log-densities */);
 int amis_dev_pass_b(const AmisView &v, int64_t P, double top, int top_finite, const double *logw, double *rel,
                     double *partial /* blocks x (2 + k1 + n k1): W, S, acc, marg */, int blocks, void *stream);
 int amis_dev_pass_c(const AmisView &v, int64_t P, const double *mean /* k1, device */, double ev, const double *rel, const double *cur,

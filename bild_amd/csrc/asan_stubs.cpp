@@ -34,7 +34,7 @@ int launch_walk(const WalkParams &, void *, void *, void *) { return 1; }
 int launch_mark_refused_rows(const int32_t *, int, int64_t, double *, void *) { return 1; }
 int amis_dev_pass_a_rows(int64_t, int64_t) { return 0; }
 int amis_dev_draw(int, int, int64_t, uint64_t, uint64_t, const double *, const double *, const uint8_t *, double *, uint8_t *, void *) { return 1; }
-int amis_dev_pass_a(const AmisView &, int64_t, int64_t, int64_t, double, double *, double *, double *, double *, double *, int *, void *, const uint8_t *, uint8_t *, int32_t *, int32_t *, int32_t *) { return 1; }
+int amis_dev_pass_a(const AmisView &, int64_t, int64_t, int64_t, double, double *, double *, double *, double *, double *, int *, void *, const uint8_t *, uint8_t *, int32_t *, int32_t *, int32_t *, double *) { return 1; }
 int amis_dev_pass_b(const AmisView &, int64_t, double, int, const double *, double *, double *, int, void *) { return 1; }
 int amis_dev_pass_c(const AmisView &, int64_t, const double *, double, const double *, const double *, double *, int, void *) { return 1; }
 } // namespace bild
