@@ -319,6 +319,89 @@ int finish(hipStream_t st, bool wait)
     return e == hipSuccess ? 0 : 1;
 }
 
+
+// Pass A for the NEW samples of a step, four lanes per sample: a new sample needs its log-density under every proposal used so
+// far (Q of them, twice: for the maximum, then for the sum) -- one lane per sample left 157 waves walking 2 Q densities each
+// while the chip looked on.  Lane `sub` of a sample's quad takes the proposals q = sub, sub + 4, ...; maximum, NaN flag and sum
+// are combined across the quad.  (What the host's loop derives from the states is written by all four lanes -- the same values --
+// so that each lane reads back its own stores.)  The sum over q is formed in four interleaved parts, (s0 + s1) + (s2 + s3): it
+// agrees with the host's sequential sum to rounding.
+constexpr int kAmisQuad = 4;
+__global__ void __launch_bounds__(kAmisBlock) pass_a_new_kernel(AmisView v, int64_t Q, int64_t lo, int64_t hi, int row0, double logQ,
+                                                                double *log_ss, double *cur, double *logd, double *logw,
+                                                                double *partial, AmisDerive dv, double *lq_keep)
+{
+    __shared__ double top_s[kAmisBlock];
+    __shared__ int nan_s;
+    const int tid = threadIdx.x, sub = tid & (kAmisQuad - 1);
+    if (tid == 0) nan_s = 0;
+    __syncthreads();
+    const int64_t p = lo + (int64_t)blockIdx.x * (kAmisBlock / kAmisQuad) + (tid >> 2);
+    const bool live = p < hi;
+    const int64_t n_new = hi - lo, colx = p - lo;
+    double cq = 0.0, mx = amis_neg_inf(), s = 0.0;
+    bool nan_q = false;
+    if (live) {
+        bool z = false;
+        for (int j = 0; j < v.k1; ++j) {
+            const double sv = v.ss[(size_t)p * v.k1 + j];
+            z |= sv == 0;
+            log_ss[(size_t)p * v.k1 + j] = sv == 0 ? 0.0 : log(sv);
+        }
+        if (dv.theta8 != nullptr) {
+            const uint8_t *t8 = dv.theta8 + (size_t)p * v.k1;
+            dv.has_zero[p] = z ? 1 : 0;
+            dv.first[p] = t8[0];
+            for (int i = 0; i < v.k1; ++i) dv.theta[(size_t)p * v.k1 + i] = t8[i];
+            for (int i = 0; i < v.k; ++i) dv.pcode[(size_t)p * v.k + i] = (i * v.n + t8[i]) * v.n + t8[i + 1];
+        }
+        for (int64_t q = sub; q < Q; q += kAmisQuad) {
+            const double lq = amis_log_q(v, q, p);
+            lq_keep[q * n_new + colx] = lq;
+            if (q == Q - 1) cq = lq;
+            nan_q |= lq != lq;
+            mx = lq > mx ? lq : mx;
+        }
+    }
+    // across the quad (all lanes take part in the exchanges; a lane without a sample carries neutral values)
+    for (int off = 1; off < kAmisQuad; off <<= 1) {
+        const double m2 = __shfl_xor(mx, off);
+        mx = m2 > mx ? m2 : mx;
+        nan_q |= __shfl_xor(nan_q ? 1 : 0, off) != 0;
+        cq += __shfl_xor(cq, off); // (exactly one lane of the quad holds it, the others 0)
+    }
+    double ld;
+    if (nan_q) {
+        ld = nan("");
+    } else {
+        if (!(mx > amis_neg_inf() && mx < -amis_neg_inf())) mx = 0.0;
+        if (live)
+            for (int64_t q = sub; q < Q; q += kAmisQuad) s += exp(lq_keep[q * n_new + colx] - mx);
+        for (int off = 1; off < kAmisQuad; off <<= 1) s += __shfl_xor(s, off);
+        ld = log(s) + mx;
+    }
+    double top = amis_neg_inf();
+    bool any_nan = false;
+    if (live && sub == 0) {
+        cur[p] = cq;
+        logd[p] = ld;
+        const double lw = v.logL[p] - ld + logQ;
+        logw[p] = lw;
+        any_nan = lw != lw;
+        top = lw == lw ? lw : top; // NaN never replaces the maximum
+    }
+    top_s[tid] = top;
+    if (any_nan) atomicOr(&nan_s, 1);
+    for (int half = kAmisBlock / 2; half > 0; half >>= 1) {
+        __syncthreads();
+        if (tid < half) top_s[tid] = top_s[tid] < top_s[tid + half] ? top_s[tid + half] : top_s[tid];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        partial[2 * (row0 + blockIdx.x)] = top_s[0];
+        partial[2 * (row0 + blockIdx.x) + 1] = nan_s ? 1.0 : 0.0;
+    }
+}
 } // namespace
 
 int amis_dev_pass_a(const AmisView &v, int64_t Q, int64_t P0, int64_t P, double logQ, double *log_ss, double *cur, double *logd,
@@ -330,14 +413,21 @@ int amis_dev_pass_a(const AmisView &v, int64_t Q, int64_t P0, int64_t P, double 
     // the samples drawn so far: one log-density each, kAmisPerLaneA per lane; the new ones: all Q proposals each (twice:
     // maximum, then sum) -- one per lane, or ten blocks would work while the rest of the chip looks on
     const int64_t per_block = (int64_t)kAmisBlock * kAmisPerLaneA;
-    const int old_blocks = (int)((P0 + per_block - 1) / per_block), new_blocks = (int)((P - P0 + kAmisBlock - 1) / kAmisBlock);
+    const int per_new = kAmisBlock / kAmisQuad; // (the rows of `partial` are laid out for the quad kernel: amis_dev_pass_a_rows)
+    const int old_blocks = (int)((P0 + per_block - 1) / per_block), new_blocks = (int)((P - P0 + per_new - 1) / per_new);
     if (old_blocks)
         hipLaunchKernelGGL(pass_a_kernel, dim3(old_blocks), dim3(kAmisBlock), 0, st, v, Q, P0, (int64_t)0, P0, kAmisPerLaneA, 0, logQ,
                            log_ss, cur, logd, logw, partial, dv, (double *)nullptr);
-    if (new_blocks)
-        hipLaunchKernelGGL(pass_a_kernel, dim3(new_blocks), dim3(kAmisBlock), 0, st, v, Q, P0, P0, P, 1, old_blocks, logQ, log_ss,
-                           cur, logd, logw, partial, dv, lq_keep);
-    *rows = old_blocks + new_blocks;
+    if (new_blocks && lq_keep)
+        hipLaunchKernelGGL(pass_a_new_kernel, dim3(new_blocks), dim3(kAmisBlock), 0, st, v, Q, P0, P, old_blocks, logQ, log_ss, cur, logd,
+                           logw, partial, dv, lq_keep);
+    int new_rows = new_blocks;
+    if (new_blocks && !lq_keep) { // (no scratch memory: one lane per sample, every density twice)
+        new_rows = (int)((P - P0 + kAmisBlock - 1) / kAmisBlock);
+        hipLaunchKernelGGL(pass_a_kernel, dim3(new_rows), dim3(kAmisBlock), 0, st, v, Q, P0, P0, P, 1, old_blocks, logQ, log_ss, cur, logd,
+                           logw, partial, dv, (double *)nullptr);
+    }
+    *rows = old_blocks + new_rows;
     return finish(st, false);
 }
 
@@ -351,8 +441,8 @@ int amis_dev_draw(int k1, int n, int64_t N, uint64_t seed, uint64_t step, const 
 
 int amis_dev_pass_a_rows(int64_t P0, int64_t P)
 {
-    const int64_t per_block = (int64_t)kAmisBlock * kAmisPerLaneA;
-    return (int)((P0 + per_block - 1) / per_block) + (int)((P - P0 + kAmisBlock - 1) / kAmisBlock);
+    const int64_t per_block = (int64_t)kAmisBlock * kAmisPerLaneA, per_new = kAmisBlock / kAmisQuad;
+    return (int)((P0 + per_block - 1) / per_block) + (int)((P - P0 + per_new - 1) / per_new);
 }
 
 int amis_dev_pass_b(const AmisView &v, int64_t P, double top, int top_finite, const double *logw, double *rel, double *partial,
