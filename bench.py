@@ -19,7 +19,7 @@ What the JSON line reports
   k_sweep, large_batch, config2_one_gpu, config3, config4, single_eval, concentrated_proposal, first_call
                         the other BASELINE configurations and the regimes a caller meets, each with its own timing;
   amis_step             whole AMIS iterations around the seam: NumPy random stream (the reference's), and draws on the device;
-  cpu_baseline          the reference's own Cython kernel on one host core.
+  cpu_baseline          the oracle's C port of the reference kernel on one host core (+ reference-equivalent figure).
 
 Multi-GPU: one process per GPU.  `--scaling weak` (default, what the driver runs): every rank evaluates its own 10k
 batch and joins ONE all-gather of the log-likelihoods per step (RCCL), as an AMIS step needs them to form the
@@ -83,26 +83,20 @@ def _cpu_baseline_loop(model, traj, ss, thetas, T, budget_s, first):
     """ the timed loop itself; runs in a child process (see cpu_baseline) """
     import helpers as H
     from oracle import oracle
-    ref = oracle.load_reference_cython()
-    kind = 'reference'
+    # The reference's Cython kernel does not travel to the GPU box (oracle/_ref/ is in .gpurunignore, SURVEY 8d): what is
+    # timed here, on every box, is this repository's C restatement of it (oracle/msrouse_logl.c, bit-pinned to the reference
+    # goldens), in the Python loop FixedkSampler.logL runs (amis.py:735-739).
     states = H.expand(ss[first:first + 8192], thetas[first:first + 8192], T)
+    arrays, w, err, x = model.arrays(), model.measurement, model.localization_error, traj[:]
 
-    class M:
-        pass
-    m = M()
-    m.models, m.measurement, m.d = model.models, model.measurement, model.d
-    m._get_noise = model._get_noise
-    if ref is None:
-        kind = 'port'
-
-        def ref(mm, prof, tr):
-            return oracle.logl(model.arrays(), model.measurement, model.localization_error, tr[:], prof[:])
-    ref(m, H.ProfileView(states[0]), traj)  # warm
+    def ref(prof):
+        return oracle.logl(arrays, w, err, x, prof)
+    ref(states[0])  # warm
     out = []
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < budget_s and len(out) < len(states):
-        out.append(ref(m, H.ProfileView(states[len(out)]), traj))
-    return kind, time.perf_counter() - t0, np.array(out)
+        out.append(ref(states[len(out)]))
+    return 'port', time.perf_counter() - t0, np.array(out)
 
 
 def _cpu_baseline_child(argv):
@@ -115,8 +109,9 @@ def _cpu_baseline_child(argv):
 
 def cpu_baseline(seed, n, T, k, S, budget_s=15.0, procs=1):
     """
-    The reference's own Cython kernel (compiled unmodified into oracle/_ref) on host cores, driven exactly like
-    FixedkSampler.logL drives it (a Python loop, amis.py:735-739), on a bounded sample of the same batch.  Every
+    The oracle's C restatement of the reference kernel (kind "port") on host cores, driven exactly like FixedkSampler.logL
+    drives the reference's (a Python loop, amis.py:735-739), on a bounded sample of the same batch; `reference_equiv`
+    converts it with the factor oracle/conversion_factor.py measured in the build container.  Every
     process is a fresh child with the BLAS pools pinned to one thread from the start: inside this process (torch
     loaded, pools limited after the fact) the same loop is 20-35 % slower, which would flatter the GPU.
     `procs` > 1: that many children at once over disjoint parts of the batch (one per core).
@@ -141,10 +136,23 @@ def cpu_baseline(seed, n, T, k, S, budget_s=15.0, procs=1):
                 dts.append(float(z['dt']))
                 outs.append(np.array(z['out']))
                 total += len(z['out'])
-    what = 'reference Cython MSRouse_logL (oracle/_ref)' if kind == 'reference' else 'oracle C port'
-    return dict(value=total / max(dts), unit='evals/s', cores=procs, kind=kind,
-                sample=f"{total} profiles of the rank-0 batch, T={T}, {max(dts):.1f} s of {what} in a Python loop "
-                       f"(amis.py:735-739), {procs} process(es), BLAS pinned to 1 thread each"), outs[0]
+    base = dict(value=total / max(dts), unit='evals/s', cores=procs, kind=kind,
+                sample=f"{total} profiles of the rank-0 batch, T={T}, {max(dts):.1f} s of the oracle's C restatement of the "
+                       f"reference kernel (oracle/msrouse_logl.c) in a Python loop (amis.py:735-739), {procs} process(es)")
+    try:
+        # reference Cython : port, measured in the BUILD CONTAINER on one core by oracle/conversion_factor.py (the reference
+        # never leaves that container: SURVEY 8d)
+        with open(os.path.join(ROOT, 'oracle', 'conversion_factor.json')) as f:
+            cf = json.load(f)
+        base['reference_equiv'] = {
+            'value': base['value'] * cf['reference_over_port'], 'unit': 'evals/s', 'factor': cf['reference_over_port'],
+            'provenance': f"{cf['script']} on {cf['measured']}: reference Cython {cf['reference_evals_per_s']:.1f} evals/s vs port "
+                          f"{cf['port_evals_per_s']:.1f} evals/s on one core of the build container ({cf['host']['cpu']}), same inputs; "
+                          "on the GPU box's EPYC host the two were 288.5 vs 243.8 evals/s = 1.18 in round 1, when the "
+                          "binary still travelled (profiles/r01_cpu_allcores.txt)"}
+    except Exception:
+        base['reference_equiv'] = None
+    return base, outs[0]
 
 
 def _cpu_share():
@@ -418,7 +426,7 @@ def main():
         }
 
     if rank == 0 and world == 1:
-        result['parity_note'] = 'every timed batch is checked below against the reference Cython kernel (parity_max_abs_diff_vs_cpu_baseline)'
+        result['parity_note'] = 'the timed batch is checked below against the oracle (C restatement of the reference Cython kernel, pinned to the reference goldens): parity_max_abs_diff_vs_cpu_baseline'
 
     # ---- the seam: FixedkSampler.logL(ss, thetas), host arrays in, host array out ----------------------------
     if traj_id is None and not args.no_seam:
@@ -747,6 +755,8 @@ def main():
             got = default_results()[:len(ref_out)]
             result['parity_max_abs_diff_vs_cpu_baseline'] = float(np.max(np.abs(got - ref_out)))
             result['speedup_vs_cpu_baseline'] = value / base['value']
+            if base.get('reference_equiv'):
+                result['speedup_vs_reference_equiv'] = value / base['reference_equiv']['value']
             if args.cpu_allcores:
                 cores = _cpu_share()
                 allc, _ = cpu_baseline(rank, n, T, k, args.states, budget_s=10.0, procs=cores)

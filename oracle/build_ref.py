@@ -12,8 +12,10 @@ lies under /root/reference into ``oracle/_ref/MSRouse_logL.<abi>.so``:
 
 No reference source is copied into the repository: the only output is the shared object,
 and ``oracle/_ref/`` is git-ignored.  The reference's own build system (setup.py /
-Makefile) is not run.  When /root/reference is absent (the GPU box) this script is a
-no-op and the pre-built .so that travelled with the snapshot is used.
+Makefile) is not run.  The binary stays in the build container: ``oracle/_ref/`` is listed in
+``.gpurunignore`` too (the reference never leaves this container).  Where
+/root/reference is absent (the GPU box) this script is a no-op and returns None; the CPU
+baseline there is the C restatement, converted with oracle/conversion_factor.json.
 """
 import os
 import shutil

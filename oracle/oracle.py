@@ -6,8 +6,9 @@ loaders for the reference's own kernels.
                                bild/src/MSRouse_logL.pyx, flavor 'numpy' follows
                                bild/src/MSRouse_logL_py.py), called through ctypes.
 * `load_reference_cython()`  : the reference's Cython kernel, compiled unmodified by
-                               oracle/build_ref.py into oracle/_ref/ (travels to the GPU
-                               box as a binary; used there as checker and CPU baseline).
+                               oracle/build_ref.py into oracle/_ref/ -- build container ONLY
+                               (oracle/_ref/ is in .gpurunignore): validates the restatement
+                               and yields oracle/conversion_factor.json; None elsewhere.
 * `load_reference_numpy()`   : the reference's NumPy kernel, loaded by path from
                                /root/reference -- available in the build container only.
 

@@ -42,7 +42,7 @@ def test_all_missing_is_zero():
 
 
 def test_prebuilt_reference_cython_matches_goldens():
-    """ the unmodified reference kernel shipped as a binary in oracle/_ref (CPU-baseline leg) """
+    """ the unmodified reference kernel, built into oracle/_ref in the build container (it does not travel: skipped elsewhere) """
     import helpers as H
     ref = oracle.load_reference_cython()
     if ref is None:
