@@ -47,6 +47,8 @@ _vp = ctypes.c_void_p
 
 _SIGNATURES = {
     'bild_abi_version': (ctypes.c_int, []),
+    'bild_config_string': (ctypes.c_char_p, []),
+    'bild_config_reload': (ctypes.c_int, []),
     'bild_last_error': (ctypes.c_char_p, []),
     'bild_set_last_error': (None, [ctypes.c_char_p]),
     'bild_comm_library': (ctypes.c_int, [ctypes.c_char_p]),
@@ -150,10 +152,20 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = restype
             fn.argtypes = argtypes
-        if handle.bild_abi_version() != 1:
+        if handle.bild_abi_version() != 2:
             raise ImportError("libbild_amd.so ABI version mismatch")
         _lib = handle
     return _lib
+
+
+def config_string():
+    """ the BILD_* environment switches in force, as the library read them ("" = defaults) """
+    return lib().bild_config_string().decode()
+
+
+def config_reload():
+    """ re-read the BILD_* environment switches (tests / tools; not while evaluations are running) """
+    check(lib().bild_config_reload())
 
 
 def exported_symbols():

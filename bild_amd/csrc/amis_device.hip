@@ -172,18 +172,20 @@ __global__ void __launch_bounds__(kAmisBlock) pass_c_kernel(AmisView v, int64_t 
 // The reference draws from NumPy's global stream (scipy.stats.dirichlet.rvs, np.random.choice, np.random.rand:
 // bild/amis.py:66-81, 223-256), and so does this package by default -- 1.0 of the 1.8 ms of a step at N = 10 000.  This is
 // the same distribution from a counter-based generator: Philox-4x32-10 keyed by the sampler's seed, one stream per
-// (step, sample); gamma variates by Marsaglia-Tsang (with the boost gamma(a) = gamma(a + 1) U^(1/a) below one), the
+// (number of intervals k + 1, index of the sample in the POOL) -- the pool index grows with every step, also a failed one, and
+// survives pickling / bild_amis_restore (a step counter did not: a restored sampler drew its first batches again); k + 1 keeps
+// the samplers of one adaptive-k run, which share the user's seed, on distinct streams; gamma variates by Marsaglia-Tsang (with the boost gamma(a) = gamma(a + 1) U^(1/a) below one), the
 // Dirichlet point as their normalised vector, the trace slot by slot from the CFC weights as bild_amis_sample_traces does.
 // Not the reference's random numbers -- the same sampler in distribution (tests: evidences agree within their errors).
 struct Philox {
     uint32_t c[4], k[2];
     uint32_t out[4];
     int have;
-    __device__ Philox(uint64_t seed, uint64_t step, uint64_t sample)
+    __device__ Philox(uint64_t seed, uint64_t stream, uint64_t sample)
     {
         c[0] = (uint32_t)sample;
         c[1] = (uint32_t)(sample >> 32);
-        c[2] = (uint32_t)step;
+        c[2] = (uint32_t)stream;
         c[3] = 0; // block counter of this stream
         k[0] = (uint32_t)seed;
         k[1] = (uint32_t)(seed >> 32);
@@ -243,13 +245,13 @@ struct Philox {
 };
 
 // one sample per lane: ss (N x k1) and the states (N x k1 bytes) written where the likelihood and the passes read them
-__global__ void __launch_bounds__(256) draw_kernel(int k1, int n, int64_t N, uint64_t seed, uint64_t step, const double *__restrict__ a,
+__global__ void __launch_bounds__(256) draw_kernel(int k1, int n, int64_t N, uint64_t seed, uint64_t first, const double *__restrict__ a,
                                                    const double *__restrict__ prob /* n x k1, [state][slot], normalised per slot */,
                                                    const uint8_t *__restrict__ trans, double *__restrict__ ss, uint8_t *__restrict__ theta8)
 {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= N) return;
-    Philox rng(seed, step, (uint64_t)r);
+    Philox rng(seed, (uint64_t)k1, first + (uint64_t)r);
     double *row = ss + (size_t)r * k1;
     double tot = 0, asum = 0;
     for (int j = 0; j < k1; ++j) {
@@ -431,10 +433,10 @@ int amis_dev_pass_a(const AmisView &v, int64_t Q, int64_t P0, int64_t P, double 
     return finish(st, false);
 }
 
-int amis_dev_draw(int k1, int n, int64_t N, uint64_t seed, uint64_t step, const double *a, const double *prob, const uint8_t *trans,
+int amis_dev_draw(int k1, int n, int64_t N, uint64_t seed, uint64_t first, const double *a, const double *prob, const uint8_t *trans,
                   double *ss, uint8_t *theta8, void *stream)
 {
-    hipLaunchKernelGGL(draw_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, k1, n, N, seed, step, a, prob, trans,
+    hipLaunchKernelGGL(draw_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, k1, n, N, seed, first, a, prob, trans,
                        ss, theta8);
     return finish((hipStream_t)stream, false);
 }

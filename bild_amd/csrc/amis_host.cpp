@@ -27,6 +27,7 @@
 
 #include "../../include/bild_amd.h"
 #include "amis_math.h"
+#include "config.h"
 #include "internal.h"
 
 namespace {
@@ -168,7 +169,7 @@ int worker_count(int64_t nchunks)
 {
     if (nchunks < 8) return 1;
     int want = 1;
-    if (const char *e = getenv("BILD_AMIS_THREADS")) want = atoi(e);
+    want = bild::config().amis_threads;
     return (int)std::max<int64_t>(1, std::min<int64_t>(want, nchunks / 2));
 }
 
@@ -678,7 +679,7 @@ static int amis_step_impl(bild_amis *m, int64_t N, const double *ss, const int64
     }
 
     // BILD_AMIS_TRACE=1: where a step spends its time (microseconds), on stderr
-    static const bool trace = getenv("BILD_AMIS_TRACE") != nullptr;
+    const bool trace = bild::config().amis_trace;
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!trace) return;
@@ -739,7 +740,7 @@ static int amis_step_impl(bild_amis *m, int64_t N, const double *ss, const int64
         if (draw) {
             const double *dp = d.draw_par;
             if (hipMemcpyAsync(d.draw_par, d.stage, par_bytes, hipMemcpyHostToDevice, st) != hipSuccess ||
-                bild::amis_dev_draw(k1, n, N, *rng_seed, (uint64_t)m->steps, dp, dp + k1, (const uint8_t *)(dp + k1 + (size_t)n * k1),
+                bild::amis_dev_draw(k1, n, N, *rng_seed, (uint64_t)P0, dp, dp + k1, (const uint8_t *)(dp + k1 + (size_t)n * k1),
                                     d.ss + (size_t)P0 * k1, d.theta8 + (size_t)P0 * k1, (void *)st)) {
                 m->err = "fused step: drawing the samples failed";
                 return BILD_ERR_HIP;

@@ -94,7 +94,7 @@ constexpr int kAmisMaxNm = 64;        // n * k1 the device passes support
 int amis_dev_pass_a_rows(int64_t P0, int64_t P); // rows of `partial` pass A writes
 // N samples from the proposal (a: k1 concentrations; prob: n x k1 slot weights, normalised per slot; trans: n x n) drawn on
 // the device from the counter-based stream (seed, step): ss (N x k1) and theta8 (N x k1) are device memory
-int amis_dev_draw(int k1, int n, int64_t N, uint64_t seed, uint64_t step, const double *a, const double *prob, const uint8_t *trans,
+int amis_dev_draw(int k1, int n, int64_t N, uint64_t seed, uint64_t first /* pool index of the first new sample */, const double *a, const double *prob, const uint8_t *trans,
                   double *ss, uint8_t *theta8, void *stream);
 // (the launches go to `stream`, a hipStream_t; nothing is waited for: the caller's copy of `partial` does that.  theta8 ...
 // theta: see AmisDerive in amis_device.hip -- null when the host has prepared the new samples)

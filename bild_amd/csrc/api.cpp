@@ -20,6 +20,7 @@
 
 #include "../../include/bild_amd.h"
 #include "common.h"
+#include "config.h"
 #include "host_linalg.h"
 #include "internal.h"
 
@@ -639,7 +640,7 @@ int ensure_prefix(const bild_model &m, const bild_trajset &ts, hipStream_t st)
     std::lock_guard<std::mutex> lk(ts.prefix_mu);
     if (ts.prefix_state != 0) return BILD_OK;
     ts.prefix_state = -1;
-    if (getenv("BILD_NO_PREFIX")) return BILD_OK;
+    if (config().no_prefix) return BILD_OK;
     if (ts.expected_evals >= 0 && ts.expected_evals < kExpectPrefix) return BILD_OK; // a few hundred evaluations: cheaper frame by frame
     const int NP = m.NPm[kModal];
     Geometry geom{};
@@ -732,7 +733,7 @@ int ensure_transients(const bild_model &m, const bild_trajset &ts, hipStream_t s
     std::lock_guard<std::mutex> lk(ts.prefix_mu);
     if (ts.trans_state != 0) return BILD_OK;
     ts.trans_state = -1;
-    if (ts.prefix_state != 1 || getenv("BILD_NO_TRANSIENTS") || getenv("BILD_NO_JUMP") || m.S < 2) return BILD_OK;
+    if (ts.prefix_state != 1 || config().no_transients || config().no_jump || m.S < 2) return BILD_OK;
     const int S = m.S;
     int64_t nb = 0;
     for (const TrajDesc &td : ts.descs) nb += (int64_t)std::max(td.T - 1, 0) * S * (S - 1);
@@ -767,9 +768,9 @@ int ensure_transients(const bild_model &m, const bild_trajset &ts, hipStream_t s
     // the state table beside it (common.h: a chain of close switches starts at its second switch): an optimisation with a
     // budget -- T x S (S - 1) x 64 records of ~1.1 KB per trajectory and chain, 141 MB for one 2-state trajectory of 1000 frames
     double *d_states = nullptr;
-    if (ok && !getenv("BILD_NO_STATES") && !(ts.expected_evals >= 0 && ts.expected_evals < kExpectPairs)) {
+    if (ok && !config().no_states && !(ts.expected_evals >= 0 && ts.expected_evals < kExpectPairs)) {
         const size_t sbytes = (size_t)ts.strans_records * prefix_record_doubles(m.NPm[kModal]) * sizeof(double);
-        static const size_t budget = getenv("BILD_STATES_MAX_BYTES") ? (size_t)atoll(getenv("BILD_STATES_MAX_BYTES")) : ((size_t)64 << 30);
+        const size_t budget = (size_t)std::max<int64_t>(config().states_max_bytes, 0);
         if (sbytes <= budget && hipMemGetInfo(&free_b, &total_b) == hipSuccess && sbytes <= free_b / 3) {
             if (hipMalloc((void **)&d_states, sbytes) != hipSuccess) {
                 d_states = nullptr;
@@ -845,17 +846,17 @@ int ensure_pairs(const bild_model &m, const bild_trajset &ts, hipStream_t st)
     std::lock_guard<std::mutex> lk(ts.prefix_mu);
     if (ts.trans2_state != 0) return BILD_OK;
     ts.trans2_state = -1;
-    if (ts.trans_state != 1 || getenv("BILD_NO_PAIRS") || m.S < 2) return BILD_OK;
+    if (ts.trans_state != 1 || config().no_pairs || m.S < 2) return BILD_OK;
     if (ts.expected_evals >= 0 && ts.expected_evals < kExpectPairs) return BILD_OK; // (the second-level tables pay from a few thousand evaluations on)
     // gaps the table covers: up to the longest converged transient of the single table, 128 at most (BILD_PAIRS_MAX_GAP: another cap --
     // slow chains, whose transients last longer, leave more pairs to the frame loop)
-    static const int gap_cap = getenv("BILD_PAIRS_MAX_GAP") ? std::max(2, atoi(getenv("BILD_PAIRS_MAX_GAP"))) : 128;
+    const int gap_cap = config().pairs_max_gap;
     const int S = m.S, G = std::min(gap_cap, ts.trans_m_max);
     if (G < 2) return BILD_OK;
     int64_t nb = 0;
     for (const TrajDesc &td : ts.descs) nb += (int64_t)std::max(td.T - 1, 0) * (G - 1) * S * (S - 1) * (S - 1);
     // (BILD_PAIRS_MAX_TASKS=<n>: another budget, for sets of many trajectories that will see hundreds of batches)
-    static const int64_t budget = getenv("BILD_PAIRS_MAX_TASKS") ? atoll(getenv("BILD_PAIRS_MAX_TASKS")) : ((int64_t)40 << 20);
+    const int64_t budget = config().pairs_max_tasks;
     if (nb == 0 || nb > budget) return BILD_OK;
     const int64_t entries = ts.trans_entries * S * G;
     const size_t bytes = (size_t)entries * sizeof(TransEntry);
@@ -929,7 +930,7 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
             return fail(BILD_ERR_UNSUPPORTED, "chains of more than %d effective modes (here %d) run on the modal path only%s%s", kMaxNP,
                         m.n, m.modal_ok ? "" : ", which is unavailable: ", m.modal_ok ? "" : m.modal_why.c_str());
         fam = m.wide ? kWide : kModalTiles;
-    } else if (mode == kDense && m.symmetric && dense_mfma_supported(m.NPm[kDense]) && !getenv("BILD_DENSE_VALU")) {
+    } else if (mode == kDense && m.symmetric && dense_mfma_supported(m.NPm[kDense]) && !config().dense_valu) {
         fam = kDenseTiles;
     }
     Geometry geom{};
@@ -937,11 +938,11 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
     if (fam == kVector) {
         // A split launch (below) sends only its chains of close switches through the frame loop -- a few per cent of a
         // batch with few switches per candidate, a third at k = 8 -- and deals them out itself, heaviest first.
-        static const bool no_split_env0 = getenv("BILD_NO_SPLIT") != nullptr;
+        const bool no_split_env0 = config().no_split;
         // (every condition of `split` below that is known here: a launch that takes the geometry of the listed frame loop and
         // then runs the WHOLE batch with it would run at one or two waves per SIMD)
         const bool may_split = mode == kModal && K1 <= kSplitMaxK1 && !tl_building && !no_split_env0 && !(flags & (BILD_NO_SPLIT | BILD_NO_JUMP | BILD_NO_PREFIX)) &&
-                               ts.trans_state == 1 && ts.d_prefix_L != nullptr && n * ts.dstar_max <= (int64_t)INT_MAX && !getenv("BILD_NO_WALK_PLAN");
+                               ts.trans_state == 1 && ts.d_prefix_L != nullptr && n * ts.dstar_max <= (int64_t)INT_MAX && !config().no_walk_plan;
         // (the first geometry of the chain length: fewest tasks per wave, and the one whose LDS leaves room for the walk plan)
         const int64_t tasks_for_geometry = may_split ? 1 : n * ts.dstar_max;
         // (the frame loop over the work lists is latency-bound: the row layout -- three mean slots, the shortest frame for a lone
@@ -972,7 +973,7 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
     const size_t walk_bytes = fam == kVector ? (size_t)geom.W * (64 / geom.G) * kWalkDoubles * sizeof(double) : 0;
     // (a CU holds OCC waves per SIMD = 4 OCC / W workgroups of this geometry, and 160 KiB of LDS for them)
     const size_t lds_per_workgroup = fam == kVector ? (size_t)160 * 1024 / (size_t)std::max(1, (4 * geom.OCC + geom.W - 1) / geom.W) : 0;
-    const bool walk_fits = fam == kVector && K1 <= kSegLds && lds + walk_bytes <= lds_per_workgroup && !getenv("BILD_NO_WALK_PLAN");
+    const bool walk_fits = fam == kVector && K1 <= kSegLds && lds + walk_bytes <= lds_per_workgroup && !config().no_walk_plan;
 
     bool timing; // this launch is bracketed by events (bild_kernel_timing: every p-th one) and counts the frames it runs
     {
@@ -988,15 +989,15 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
     p.traj_id = d_traj_id;
     if (fam == kVector) {
         p.order = d_order;
-        p.no_jump = (flags & BILD_NO_JUMP) || getenv("BILD_NO_JUMP") ? 1 : 0;
+        p.no_jump = (flags & BILD_NO_JUMP) || config().no_jump ? 1 : 0;
         if (mode == kModal && K1 > 0 && !(flags & BILD_NO_PREFIX)) {
             const int64_t seen = tl_building ? 0 : (ts.evals_seen += n);
-            static const char *after_env = getenv("BILD_TABLES_AFTER"); // experiments only: delay the tables
-            const int64_t prefix_after = after_env ? atoll(after_env) : kPrefixAfter;
-            const int64_t transients_after = after_env ? atoll(after_env) : kTransientsAfter;
+            const bool after_env = config().tables_after >= 0; // experiments only: delay the tables
+            const int64_t prefix_after = after_env ? config().tables_after : kPrefixAfter;
+            const int64_t transients_after = after_env ? config().tables_after : kTransientsAfter;
             if (ts.prefix_state == 0 && seen >= prefix_after) ensure_prefix(m, ts, st);
             if (ts.prefix_state == 1) p.prefix = ts.d_prefix;
-            static const bool no_states = getenv("BILD_NO_STATES") != nullptr;
+            const bool no_states = config().no_states;
             if (tl_building == 1) {
                 p.trans_dump = ts.d_trans;
                 p.strans_dump = ts.d_strans;
@@ -1048,7 +1049,7 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
     // (BILD_NO_SPLIT=1).  Also the place where (s, theta) input becomes segment lists.
     const bool st_in = sp && sp->d_ss;
     if (st_in && K1 > kSplitMaxK1) return fail(BILD_ERR_INVALID, "internal: (s, theta) input with %d segments", K1);
-    static const bool no_split_env = getenv("BILD_NO_SPLIT") != nullptr;
+    const bool no_split_env = config().no_split;
     const bool no_split = no_split_env || (flags & BILD_NO_SPLIT);
     const bool split = fam == kVector && mode == kModal && K1 <= kSplitMaxK1 && !tl_building && !no_split && p.trans != nullptr &&
                        p.walk_lds && ts.d_prefix_L != nullptr && p.ntasks <= (int64_t)INT_MAX;
@@ -1172,7 +1173,7 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
     const int64_t tasks_per_block = fam == kWide ? 1 : fam != kVector ? 16 : (int64_t)geom.W * geom.tasks_per_wave();
     int64_t blocks = (p.ntasks + tasks_per_block - 1) / tasks_per_block;
     // (work lists: one residency of the chip at most -- most of the tasks never reach the frame loop)
-    static const int work_blocks = getenv("BILD_WORK_BLOCKS") ? atoi(getenv("BILD_WORK_BLOCKS")) : 0;
+    const int work_blocks = config().work_blocks;
     const int64_t max_blocks = split ? (work_blocks > 0 ? work_blocks : 256 * std::max(geom.OCC, 1)) : 256 * 16;
     const int grid = (int)std::min<int64_t>(std::max<int64_t>(blocks, 1), max_blocks);
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1231,8 +1232,8 @@ bool schedule(const bild_model &m, const bild_trajset &ts, int64_t n, int K1, co
 {
     int mode;
     if (n < 2 || K1 < 2 || n > INT_MAX || pick_mode(m, flags, &mode) || mode != kModal || m.wide || m.mid) return false;
-    if ((flags & BILD_NO_PREFIX) || ts.prefix_state < 0 || getenv("BILD_NO_PREFIX") || getenv("BILD_NO_SCHEDULE")) return false;
-    const bool jumps = !(flags & BILD_NO_JUMP) && !getenv("BILD_NO_JUMP");
+    if ((flags & BILD_NO_PREFIX) || ts.prefix_state < 0 || config().no_prefix || config().no_schedule) return false;
+    const bool jumps = !(flags & BILD_NO_JUMP) && !config().no_jump;
     // with jumps but without a transient table every switch costs about the same wherever it is: nothing to sort by
     if (jumps && ts.trans_state != 1) return false;
     // Measured on the 10k batch (profiles/r02_transients.txt): with the tables the order is worth 22 us of kernel time and
@@ -1300,7 +1301,7 @@ bool schedule(const bild_model &m, const bild_trajset &ts, int64_t n, int K1, co
         // order: then candidates of equal work share a wave (the sorted order as it is), heaviest waves first
         // (`profiles/r02_launch_order.txt`: 80 000 candidates 220 -> 157 us, configs[2]'s 256 000 1.77 -> 0.92 ms; a batch
         // that fits the chip once is better off spread even when every wave has busy rows: 10 000 x k = 8, 123 vs 152 us).
-        static const char *mode_env = getenv("BILD_SCHED_MODE"); // experiments: "spread" / "sorted" whatever the batch
+        const char *mode_env = config().sched_mode.empty() ? nullptr : config().sched_mode.c_str(); // experiments: "spread" / "sorted" whatever the batch
         const int64_t slots = (int64_t)256 * geom.OCC * geom.W * rpw;
         int64_t busy = 0;
         while (busy < n && work[sorted[busy]] > 0) ++busy;
@@ -1366,10 +1367,10 @@ int device_order(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
     if (n < 2 || K1 < 2 || n > INT_MAX || m.wide || m.mid || !m.modal_ok) return 1;
     const unsigned path = flags & 0xFu;
     if (path != BILD_PATH_AUTO && path != BILD_PATH_MODAL) return 1;
-    if ((flags & (BILD_NO_PREFIX | BILD_NO_JUMP)) || getenv("BILD_NO_PREFIX") || getenv("BILD_NO_JUMP") || getenv("BILD_NO_SCHEDULE")) return 1;
+    if ((flags & (BILD_NO_PREFIX | BILD_NO_JUMP)) || config().no_prefix || config().no_jump || config().no_schedule) return 1;
     if (ts.prefix_state != 1 || ts.trans_state != 1) return 1;
     // a split launch orders its frame loop itself (work lists by expected work)
-    if (K1 <= kSplitMaxK1 && !getenv("BILD_NO_SPLIT")) return 1;
+    if (K1 <= kSplitMaxK1 && !config().no_split) return 1;
     Geometry geom{};
     if (!geometry_for(m.NPm[kModal], kModal, n * ts.dstar_max, ts.means_max, &geom)) return 1;
     if (geom.tasks_per_wave() % ts.dstar_max != 0) return 1;
@@ -1394,7 +1395,7 @@ struct StageClock {
     bool on;
     std::chrono::steady_clock::time_point t0;
     double acc[6] = {0, 0, 0, 0, 0, 0};
-    StageClock() : on(getenv("BILD_TRACE_STAGED") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    StageClock() : on(config().trace_staged), t0(std::chrono::steady_clock::now()) {}
     void lap(int i)
     {
         if (!on) return;
@@ -1460,7 +1461,7 @@ int run_staged(const bild_model *m, const bild_trajset *ts, int64_t n, int K1, c
     // Batches of up to 50 000 rows on one trajectory: the walk kernel reads the (s, theta) rows straight out of the pinned
     // block over PCIe (450 KB for the 10k batch) -- no host-to-device copy to enqueue and wait for: 136 -> 130 us per call.
     // BILD_IN_VIA_COPY=1: always through a copy in HBM.
-    static const bool in_copy = getenv("BILD_IN_VIA_COPY") != nullptr;
+    const bool in_copy = config().in_via_copy;
     const bool direct_in = !in_copy && st_payload && !traj_id && n <= 50000;
     if (st_payload) {
         d_start = (int32_t *)(d_base + copy_cap);
@@ -1485,7 +1486,7 @@ int run_staged(const bild_model *m, const bild_trajset *ts, int64_t n, int K1, c
     }
     // Results of a host-buffer call: the kernels write them straight into the pinned block (80 KB of posted writes over
     // PCIe for the 10k batch) -- no device-to-host copy to launch and wait for.  BILD_OUT_VIA_COPY=1: through HBM and a copy.
-    static const bool out_via_copy = getenv("BILD_OUT_VIA_COPY") != nullptr;
+    const bool out_via_copy = config().out_via_copy;
     double *d_out = d_out_user ? d_out_user : (out_via_copy ? (double *)m->ws_out.ptr : (double *)m->h_out.ptr);
     hipStream_t st = d_out_user ? st_user : m->stream;
     if (!direct_in) HIP_TRY(hipMemcpyAsync(d_base, h_base, in_bytes, hipMemcpyHostToDevice, st));
@@ -1815,6 +1816,7 @@ int bild_trajset_create(const bild_model *m, int n_traj, const int32_t *T, const
 int bild_trajset_expect(bild_trajset *ts, int64_t evaluations)
 {
     if (!ts) return fail(BILD_ERR_INVALID, "NULL handle");
+    if (evaluations < 0) return fail(BILD_ERR_INVALID, "a negative number of expected evaluations");
     if (ts->prefix_state != 0) return fail(BILD_ERR_INVALID, "the trajectory set has been evaluated on already: declare the expected use first");
     ts->expected_evals = evaluations;
     return BILD_OK;
@@ -2053,9 +2055,11 @@ static int st_row(const double *s, const int64_t *th, int K1, int S, double Tm1,
             const double pos = acc * Tm1;
             // floor(pos) for 0 <= pos < 2^31 is the truncating conversion (one SSE2 instruction, no libm call).  The
             // intrinsic is defined for every input: NaN and out-of-range values give INT64_MIN, which the unsigned range
-            // test below rejects together with negative positions.
+            // test below rejects.  A position in (-1, 0) would truncate to 0 where np.floor gives -1 (the reference then
+            // builds a profile whose FIRST interval is empty, amis.py:685-693): refused, like every negative position.
             const int64_t fl = _mm_cvttsd_si64(_mm_set_sd(pos));
             ok &= (uint64_t)fl < 2147483646ull;
+            ok &= !(pos < 0.0);
             const int32_t idx = (int32_t)fl + 1;
             ok &= idx >= prev;
             prev = idx;
@@ -2095,7 +2099,7 @@ static int logl_st_impl(const bild_model *m, const bild_trajset *ts, int64_t n, 
     // The rows go up as they are -- float64 interval lengths, states narrowed to one byte -- and the walk kernel turns
     // them into switch frames on the device (walk.hip; same operations as st_row below, bit for bit).  Lists of more
     // segments than that kernel holds in registers are converted here.
-    static const bool host_convert = getenv("BILD_ST_ON_HOST") != nullptr;
+    const bool host_convert = config().st_on_host;
     if (K1 <= kSplitMaxK1 && !host_convert)
         return run_staged(m, ts, n, K1, traj_id, flags, out, d_out, (hipStream_t)hip_stream, true, [&](char *payload) -> int {
             const size_t nseg = (size_t)n * K1;

@@ -1,0 +1,50 @@
+// The library's environment switches, read ONCE (at first use) into one struct -- a dozen getenv calls per launch were
+// 1-2 us of a 17 us small-batch call, and nobody could see which experiment switches a process was running under.
+// bild_config_string() (C ABI) prints the active set; bild_config_reload() re-reads the environment (tests and tools
+// that flip a switch inside one process; not to be called while evaluations are running).
+#pragma once
+#include <stdint.h>
+#include <string>
+
+namespace bild {
+
+struct Config {
+    // tables of a trajectory set (decided at the set's first evaluation)
+    bool no_prefix = false;      // BILD_NO_PREFIX        never build a prefix table
+    bool no_transients = false;  // BILD_NO_TRANSIENTS    no transient table
+    bool no_pairs = false;       // BILD_NO_PAIRS         no pair table
+    bool no_states = false;      // BILD_NO_STATES        no transient state table
+    int64_t states_max_bytes = (int64_t)64 << 30; // BILD_STATES_MAX_BYTES
+    int pairs_max_gap = 128;                      // BILD_PAIRS_MAX_GAP
+    int64_t pairs_max_tasks = (int64_t)40 << 20;  // BILD_PAIRS_MAX_TASKS
+    int64_t tables_after = -1;                    // BILD_TABLES_AFTER     experiments: delay the tables (-1: the built-in thresholds)
+    // launches
+    bool no_jump = false;            // BILD_NO_JUMP            frame by frame behind the first switch
+    bool no_split = false;           // BILD_NO_SPLIT           single launch
+    bool no_walk_plan = false;       // BILD_NO_WALK_PLAN
+    bool no_schedule = false;        // BILD_NO_SCHEDULE
+    bool no_listed_geometry = false; // BILD_NO_LISTED_GEOMETRY
+    bool dense_valu = false;         // BILD_DENSE_VALU         dense path on the vector pipe
+    bool no_fused_launch = false;    // BILD_NO_FUSED_LAUNCH    walk and frame loop as two launches (A/B against the fused grid)
+    int geom = -1;                   // BILD_GEOM               force a geometry id
+    int work_blocks = 0;             // BILD_WORK_BLOCKS
+    int wide_threads = 0;            // BILD_WIDE_THREADS       256 / 512 / 1024
+    int walk_debug = 0;              // BILD_WALK_DEBUG
+    std::string sched_mode;          // BILD_SCHED_MODE         "spread" / "sorted"
+    // the host-buffer seam
+    bool in_via_copy = false;  // BILD_IN_VIA_COPY
+    bool out_via_copy = false; // BILD_OUT_VIA_COPY
+    bool st_on_host = false;   // BILD_ST_ON_HOST
+    bool trace_staged = false; // BILD_TRACE_STAGED
+    // AMIS bookkeeping / the inference driver
+    bool amis_trace = false; // BILD_AMIS_TRACE
+    int amis_threads = 1;    // BILD_AMIS_THREADS      threads of one sampler's passes over a large pool
+    int host_threads = 0;    // BILD_HOST_THREADS      worker threads of the inference driver (0: min(8, cores))
+    // everything that differs from the defaults, as "NAME=value NAME=value" ("" when nothing is set)
+    std::string active;
+};
+
+const Config &config();
+void config_reload();
+
+} // namespace bild

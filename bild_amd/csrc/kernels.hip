@@ -43,6 +43,7 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include "config.h"
 #include "common.h"
 
 // expected frames of a wave's busiest row from which it asks for issue priority 1 / 2 / 3 (logl_kernel, "wave priority")
@@ -1350,8 +1351,8 @@ int padded_rows(int n_rows)
 
 bool geometry_for(int NP, int mode, int64_t ntasks, int means, Geometry *g)
 {
-    if (const char *ov = getenv("BILD_GEOM")) {
-        const int id = atoi(ov);
+    if (bild::config().geom >= 0) {
+        const int id = bild::config().geom;
         for (const Geometry &c : kGeoms)
             if (c.id == id && c.NP == NP && c.mean_slots() >= means) {
                 *g = c;
@@ -1392,7 +1393,7 @@ bool geometry_for(int NP, int mode, int64_t ntasks, int means, Geometry *g)
 // per SIMD -- two reloads per frame, dozens per comparison -- stays in registers there).
 bool listed_geometry(const Geometry &from, Geometry *g)
 {
-    if (getenv("BILD_GEOM") || getenv("BILD_NO_LISTED_GEOMETRY")) return false;
+    if (bild::config().geom >= 0 || bild::config().no_listed_geometry) return false;
     const int to = from.id == 21 ? 23 : from.id == 7 ? 24 : from.id == 9 ? 25 : -1;
     for (const Geometry &c : kGeoms)
         if (c.id == to) {

@@ -26,6 +26,7 @@
 #include <limits.h>
 #include <stdlib.h>
 
+#include "config.h"
 #include "common.h"
 
 namespace bild {
@@ -70,9 +71,9 @@ __device__ __forceinline__ int walk_task(const WalkParams &p, const int64_t task
                 if (i + 1 < K1) {
                     acc = __dadd_rn(acc, s[i]);            // np.cumsum: sequential
                     const double pos = __dmul_rn(acc, Tm1); // one multiplication, not fused with the sum
-                    // floor for 0 <= pos < 2^31 is the truncating conversion; the host's range test (api.cpp: st_row)
-                    // accepts -1 < pos (which truncates to 0) and rejects NaN
-                    const bool in_range = pos > -1.0 && pos < 2147483646.0;
+                    // floor for 0 <= pos < 2^31 is the truncating conversion; as on the host (api.cpp: st_row) a negative
+                    // position -- where truncation and np.floor differ -- and NaN are refused
+                    const bool in_range = pos >= 0.0 && pos < 2147483646.0;
                     const int idx = in_range ? (int)pos + 1 : INT_MAX;
                     ok = ok && in_range && idx >= prev;
                     prev = idx;
@@ -370,7 +371,7 @@ int launch_mark_refused_rows(const int32_t *seg_start, int K1, int64_t n, double
 int launch_walk(const WalkParams &p, void *stream, void *ev_start, void *ev_stop)
 {
     if (p.n <= 0) return 0;
-    if (const char *dbg = getenv("BILD_WALK_DEBUG")) const_cast<WalkParams &>(p).debug = atoi(dbg);
+    if (bild::config().walk_debug) const_cast<WalkParams &>(p).debug = bild::config().walk_debug;
     if (p.n * p.dstar_max > (int64_t)INT_MAX) return (int)hipErrorInvalidValue; // task indices in the work lists are int32
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     hipEvent_t ev0 = reinterpret_cast<hipEvent_t>(ev_start), ev1 = reinterpret_cast<hipEvent_t>(ev_stop);

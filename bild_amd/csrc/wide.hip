@@ -22,6 +22,7 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include "config.h"
 #include "common.h"
 
 namespace bild {
@@ -234,8 +235,8 @@ __global__ void __launch_bounds__(kThreads) logl_wide_kernel(const KParams p, co
 // env BILD_WIDE_THREADS overrides (256 / 512 / 1024).
 int wide_threads(int NP)
 {
-    if (const char *e = getenv("BILD_WIDE_THREADS")) {
-        const int t = atoi(e);
+    if (bild::config().wide_threads) {
+        const int t = bild::config().wide_threads;
         if (t == 256 || t == 512 || t == 1024) return t;
     }
     return NP <= 68 ? 256 : (NP <= 92 ? 512 : 1024);

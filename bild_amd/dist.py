@@ -221,9 +221,29 @@ class ShardedModel:
         comm.allgather(local.ptr, gathered.ptr, m, stream=0)          # default stream: ordered behind the kernel
         host = gathered.to_host(m * comm.world)                       # the one device -> host copy of the step
         self.host_copies += 1
-        if hi > lo:
-            self._model.check_st_rows()
+        self._verdict(host, hi > lo, ss, thetas, traj)
         return np.concatenate([host[r * m:r * m + sizes[r]] for r in range(comm.world)])
+
+    def _verdict(self, gathered, had_shard, ss, thetas, traj):
+        """
+        Rows the device refused (no points on the simplex) must fail the step on EVERY rank, as the unsharded `logL` does --
+        were only the rank that owns the row to raise, the others would go on to the next collective and hang there.  A
+        refused row comes back as NaN, and every rank holds the full batch (the AMIS loop is replicated): whenever the
+        gathered vector contains a NaN, every rank converts the full batch on the host (`bild_segments_from_st`, the
+        conversion the kernels mirror), which raises for exactly the rows the device refuses -- the same exception, for
+        the same row, everywhere.  A NaN that a legitimate row produced costs one conversion and passes through.
+        """
+        from . import _lib
+        refused = None
+        if had_shard:
+            try:
+                self._model.check_st_rows()      # waits for ALL pending to_device calls of the model and forgets the verdict
+            except _lib.BildAmdError as err:
+                refused = err
+        if np.isnan(gathered).any():
+            _lib.segments_from_st(np.asarray(ss, dtype=np.float64), np.asarray(thetas), len(traj), int(self._model.nStates))
+        if refused is not None:     # (cannot happen without a NaN in the gathered vector; never swallow a verdict)
+            raise refused
 
     def logL_st_batch(self, ss, thetas, traj):
         if self._comm is not None:
@@ -254,13 +274,21 @@ class ShardedModel:
             dist.all_gather_into_tensor(gathered, local, group=self._group)      # same stream: ordered behind the kernel
             host = gathered.cpu().numpy()                                        # the one device -> host copy of the step
             self.host_copies += 1
-            if hi > lo:
-                self._model.check_st_rows()      # rows the device refused (no points on the simplex): raises, as `logL` does
+            self._verdict(host, hi > lo, ss, thetas, traj)
             return np.concatenate([host[r * m:r * m + sizes[r]] for r in range(world)])
-        local = np.asarray(self._model.logL_st_batch(ss[lo:hi], thetas[lo:hi], traj), dtype=np.float64) if hi > lo \
-            else np.empty(0)
-        full = all_gather_logl_ragged(torch.from_numpy(local).to(device), sizes, self._group)
-        return full.cpu().numpy()
+        local, refused = np.empty(0), None
+        if hi > lo:
+            try:
+                local = np.asarray(self._model.logL_st_batch(ss[lo:hi], thetas[lo:hi], traj), dtype=np.float64)
+            except Exception as err:    # (a refused row: the collective below must still be joined, see `_verdict`)
+                local, refused = np.full(hi - lo, np.nan), err
+        full = all_gather_logl_ragged(torch.from_numpy(local).to(device), sizes, self._group).cpu().numpy()
+        if np.isnan(full).any():
+            from . import _lib
+            _lib.segments_from_st(np.asarray(ss, dtype=np.float64), np.asarray(thetas), len(traj), int(self._model.nStates))
+        if refused is not None:
+            raise refused
+        return full
 
 
 def sample_many_distributed(trajs, model, group=None, seed=None, gather='all', **kwargs):

@@ -187,8 +187,11 @@ class MultiStateRouse(MultiStateModel):
         Device-resident set of trajectories (uploaded once, reused across AMIS steps).
 
         trajs : a trajectory or a list of trajectories
-        expect : optional, the number of evaluations the set will see in total (`bild_trajset_expect`; honoured when the set
-            is created by this call): a few single evaluations per trajectory are cheaper without the set's tables
+        expect : optional, the number of evaluations the set will see in total (`bild_trajset_expect`): a few single
+            evaluations per trajectory are cheaper without the set's tables.  The declaration decides which tables the set
+            builds (none below 300 evaluations, prefix + transient tables below 3000, all of them above or when nothing is
+            declared) and is therefore part of the cache key: a set declared for ten evaluations is never handed to an AMIS
+            run (which asks without a declaration), and the other way round.
 
         The cache is keyed by the IDENTITY of the trajectory objects, and an entry is trusted while the address and shape
         of each trajectory's data, the localization errors in force and a content guard (the sum of the bit patterns of
@@ -202,7 +205,10 @@ class MultiStateRouse(MultiStateModel):
         single = not isinstance(trajs, (list, tuple))
         items = (trajs,) if single else tuple(trajs)
         prints, arrs = self._fingerprints(items)
-        key = tuple(id(t) if p[0] is not None else p for t, p in zip(items, prints))
+        if expect is not None and expect < 0:
+            raise ValueError("expect must be a non-negative number of evaluations")
+        table_class = 2 if expect is None or expect >= 3000 else (1 if expect >= 300 else 0)   # (api.cpp: kExpectPrefix, kExpectPairs)
+        key = (table_class,) + tuple(id(t) if p[0] is not None else p for t, p in zip(items, prints))
         hit = self._trajsets.get(key)
         if hit is not None:
             ts, kept, old_prints = hit

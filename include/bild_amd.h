@@ -29,7 +29,10 @@
 extern "C" {
 #endif
 
-#define BILD_AMD_ABI_VERSION 1
+/* 2: round 4 -- bild_config_string / bild_config_reload, the inference driver (bild_run_*), the direct exchange
+ *    (bild_comm_direct_*); negative cumulative positions of an (s, theta) row are refused on every path.
+ * 1: rounds 1-3 (the version constant was not bumped while entry points were added). */
+#define BILD_AMD_ABI_VERSION 2
 
 typedef enum bild_status {
     BILD_OK              = 0,
@@ -83,6 +86,14 @@ typedef struct bild_trajset bild_trajset;
 int         bild_abi_version(void);
 const char *bild_last_error(void);
 void        bild_set_last_error(const char *msg); /* for the library's own translation units */
+
+/* The experiment switches of the library are environment variables (BILD_NO_SPLIT, BILD_NO_STATES, BILD_PAIRS_MAX_TASKS ...:
+ * csrc/config.h lists them all).  They are read ONCE, at the first use of the library in a process.
+ * bild_config_string(): the switches that are set, as "NAME=value NAME=value" ("" when the defaults are in force) -- what
+ * a bug report should carry.  bild_config_reload(): read the environment again (tests and tools that flip a switch inside
+ * one process; must not run concurrently with evaluations; tables a trajectory set has built already stay as they are). */
+const char *bild_config_string(void);
+int         bild_config_reload(void);
 
 /* Number of visible GPUs (0 without a device; never fails on a CPU-only host). */
 int bild_device_count(int *count);
@@ -203,7 +214,10 @@ int bild_logl_segments(const bild_model *m, const bild_trajset *ts, int64_t n, i
  * as they are: ss (n x K1 float64, rows on the simplex), thetas (n x K1 int64).  The switch frames are computed here
  * exactly as FixedkSampler.st2profile does (bild/amis.py:685-688: sequential cumsum, times (T-1), floor, +1; T is the
  * length of the sample's trajectory), written straight into pinned staging memory and shipped with one copy.
- * Rows with a negative or non-finite entry are refused (BILD_ERR_INVALID).  Host buffers, synchronous. */
+ * A row is refused (BILD_ERR_INVALID) when one of its cumulative positions cumsum(s)[i] * (T-1) is negative, non-finite,
+ * >= 2^31 or smaller than the one before it -- i.e. whenever it is not a point on the simplex in a way that would change
+ * the profile (the reference does not check: np.floor of a negative position gives switch index 0 and a profile whose
+ * first interval is empty).  Host buffers, synchronous. */
 int bild_logl_st(const bild_model *m, const bild_trajset *ts, int64_t n, int K1,
                  const double *ss, const int64_t *thetas, const int32_t *traj_id,
                  unsigned flags, double *out);

@@ -23,7 +23,7 @@ def test_header_symbols_exported(built_lib):
         assert hasattr(built_lib, name), f"{name} declared in include/bild_amd.h but not exported"
     from bild_amd import _lib
     assert declared == set(_lib.exported_symbols())
-    assert built_lib.bild_abi_version() == 1
+    assert built_lib.bild_abi_version() == 2
 
 
 def test_loads_without_gpu_and_fails_loudly(built_lib):
@@ -178,3 +178,41 @@ sys.exit(0 if (rc == _lib.ERR_UNSUPPORTED and rc2 == _lib.ERR_UNSUPPORTED and "n
         env['BILD_AMD_LIB'] = os.environ['BILD_AMD_LIB']
     res = subprocess.run([sys.executable, '-c', code, root, str(tmp_path)], capture_output=True, text=True, env=env, timeout=120)
     assert res.returncode == 0, res.stdout + res.stderr
+
+
+def test_config_is_read_once_and_reported(built_lib, monkeypatch):
+    """ the BILD_* switches: read once into one struct, visible through bild_config_string, re-read only on request """
+    from bild_amd import _lib
+    _lib.config_reload()
+    before = _lib.config_string()
+    monkeypatch.setenv('BILD_NO_SPLIT', '1')
+    monkeypatch.setenv('BILD_PAIRS_MAX_TASKS', '12345')
+    assert _lib.config_string() == before                      # setting a variable changes nothing until a reload
+    _lib.config_reload()
+    now = _lib.config_string().split()
+    assert 'BILD_NO_SPLIT=1' in now and 'BILD_PAIRS_MAX_TASKS=12345' in now
+    monkeypatch.delenv('BILD_NO_SPLIT')
+    monkeypatch.delenv('BILD_PAIRS_MAX_TASKS')
+    _lib.config_reload()
+    assert _lib.config_string() == before
+
+
+def test_negative_cumulative_position_is_refused(built_lib):
+    """
+    bild/amis.py:685-688 takes np.floor of cumsum(s) * (T - 1): a position in (-1, 0) gives switch index 0, i.e. a profile
+    whose FIRST interval is empty.  A truncating conversion would give index 1 instead -- silently another profile --, so
+    such rows are refused on every path (include/bild_amd.h: bild_logl_st), as the header says.
+    """
+    from bild_amd import _lib
+    ss = np.array([[-1e-9, 0.5, 0.5 + 1e-9]])
+    thetas = np.array([[0, 1, 0]])
+    T = 100
+    assert (np.floor(np.cumsum(ss[0])[:-1] * (T - 1)).astype(int) + 1).tolist() == [0, 50]     # what the reference computes
+    with pytest.raises(_lib.BildAmdError, match="simplex"):
+        _lib.segments_from_st(ss, thetas, T, 2)
+    ok = np.array([[0.0, 0.5, 0.5], [1e-300, 0.5, 0.5]])       # zero and tiny positive first intervals are fine
+    a, _ = _lib.segments_from_st(ok, np.array([[0, 1, 0]] * 2), T, 2)
+    assert a.tolist() == [[0, 1, 50], [0, 1, 50]]
+    # -0.0 is not negative: np.floor(-0.0) + 1 = 1, and so here
+    a, _ = _lib.segments_from_st(np.array([[-0.0, 0.5, 0.5]]), thetas, T, 2)
+    assert a.tolist() == [[0, 1, 50]]

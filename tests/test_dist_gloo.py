@@ -289,3 +289,49 @@ def test_library_collective_without_pytorch(built_lib, tmp_path):
     r = subprocess.run([sys.executable, '-c', _LIBCOMM_SCRIPT, ROOT, str(tmp_path / 'comm.id')], env=env, capture_output=True,
                        text=True, timeout=300)
     assert 'LIBCOMM_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def _refused_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import bild_amd
+    from bild_amd import _lib
+    from bild_amd.dist import ShardedModel
+    from amis_cases import _table
+    from test_core import _SegmentTableModel
+
+    class Strict(_SegmentTableModel):      # refuses what the GPU entry refuses (the conversion raises on the owner's shard)
+        def logL_st_batch(self, ss, thetas, traj):
+            _lib.segments_from_st(ss, thetas, len(traj), 2)
+            return super().logL_st_batch(ss, thetas, traj)
+    table = _table(7, 2, 40, [11, 29])
+    model = ShardedModel(Strict([table]))
+    traj = bild_amd.Trajectory(np.zeros((40, 1)))
+    rng = np.random.default_rng(5)
+    ss = rng.dirichlet(np.ones(3), size=20)
+    thetas = np.tile([0, 1, 0], (20, 1))
+    good = model.logL_st_batch(ss, thetas, traj)
+    bad = ss.copy()
+    bad[15, 0] = -0.2                       # a row of rank 1's shard that is no point on the simplex
+    try:
+        model.logL_st_batch(bad, thetas, traj)
+        outcome = 'no error'
+    except _lib.BildAmdError as err:
+        outcome = 'refused: ' + str(err)
+    again = model.logL_st_batch(ss, thetas, traj)     # the ranks are still in step: the next collective works
+    ret[rank] = (outcome, bool(np.array_equal(good, again)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_refused_row_fails_the_step_on_every_rank_world2():
+    """ round-3 advisor finding: only the rank that owned a refused row raised; the others went on and hung """
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_refused_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+        out = dict(ret)
+    assert out[0][0].startswith('refused') and out[0][0] == out[1][0] and 'sample 15' in out[0][0]
+    assert out[0][1] and out[1][1]
