@@ -104,6 +104,23 @@ _SIGNATURES = {
     'bild_amis_step_device_rng': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint, _dp]),
     'bild_amis_pool_samples': (ctypes.c_int, [_vp, _dp, _vp]),
     'bild_interval_marginals': (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int64, _ip, _ip, _dp, _dp]),
+    # the inference driver (run_host.cpp)
+    'bild_run_create': (ctypes.c_int, [ctypes.c_int, _ip, ctypes.c_int, _vp, _vp, ctypes.c_int, _dp, _dp, _dp, _vp, _ip,
+                                       ctypes.POINTER(_vp)]),
+    'bild_run_destroy': (ctypes.c_int, [_vp]),
+    'bild_run_error': (ctypes.c_char_p, [_vp]),
+    'bild_run_plan': (ctypes.c_int, [_vp, _vp, ctypes.POINTER(_vp)]),
+    'bild_run_round': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_uint, _dp, _dp, _dp]),
+    'bild_run_stage': (ctypes.c_int, [_vp, _dp, _dp]),
+    'bild_run_rows': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(_vp),
+                                     ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
+    'bild_run_finish': (ctypes.c_int, [_vp, _dp, _dp]),
+    'bild_run_traj_info': (ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.POINTER(ctypes.c_char_p)]),
+    'bild_run_traj_log': (ctypes.c_int, [_vp, ctypes.c_int, _ip, _ip, _dp, _dp, _dp]),
+    'bild_run_sampler_info': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp]),
+    'bild_run_sampler_data': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _dp, _dp, _vp, _dp]),
+    'bild_run_take_core': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_vp)]),
+    'bild_run_totals': (ctypes.c_int, [_vp, _vp]),
     'bild_choice_counts': (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, _dp, _dp, _dp, ctypes.c_double, _vp, _vp, _vp, _vp]),
 }
 
@@ -632,6 +649,135 @@ def _amis_pool_samples(self):
 
 AmisCore.step_device_rng = _amis_step_device_rng
 AmisCore.pool_samples = _amis_pool_samples
+
+
+def _adopt_amis_core(handle, n, k1):
+    """ an `AmisCore` around native bookkeeping that already exists (bild_run_take_core); the wrapper owns it from now on """
+    core = AmisCore.__new__(AmisCore)
+    core._h = handle
+    core.n = n
+    core.k1 = k1
+    return core
+
+
+class RunSettings(ctypes.Structure):
+    """ bild_run_settings (include/bild_amd.h) """
+    _fields_ = [('init_runs', ctypes.c_int32), ('k_lookahead', ctypes.c_int32), ('k_max', ctypes.c_int32), ('reserved', ctypes.c_int32),
+                ('certainty_in_k', ctypes.c_double), ('dE', ctypes.c_double), ('N', ctypes.c_int64),
+                ('concentration_brake', ctypes.c_double), ('polarization_brake', ctypes.c_double), ('max_fev', ctypes.c_int64),
+                ('max_fcomplete', ctypes.c_int64), ('choice_samplesize', ctypes.c_int64)]
+
+
+class RunHandle:
+    """
+    The inference driver (include/bild_amd.h, "the inference driver"; csrc/run_host.cpp): the adaptive-k loops of many
+    trajectories, one round at a time.  `bild_amd.core.sample_many` drives it.
+    """
+
+    def __init__(self, T, transitions, settings, per_k):
+        """
+        T : trajectory lengths; transitions : (n, n) bool; settings : dict of the fields of `RunSettings`;
+        per_k : for k = 0, 1, ...: (logp0 (n, k+1), logprior, n_total, traces (m, k+1) int or None)
+        """
+        trans = np.ascontiguousarray(np.asarray(transitions) != 0, dtype=np.uint8)
+        self.n = trans.shape[0]
+        self.n_traj = len(T)
+        Ts = i32(np.asarray(T))
+        st = RunSettings(**settings)
+        logp0 = f64(np.concatenate([np.asarray(p[0], dtype=np.float64).reshape(-1) for p in per_k]))
+        logprior = f64([p[1] for p in per_k])
+        n_total = f64([p[2] for p in per_k])
+        n_traces = np.array([0 if p[3] is None else len(p[3]) for p in per_k], dtype=np.int64)
+        given = [np.asarray(p[3], dtype=np.int32).reshape(-1) for p in per_k if p[3] is not None and len(p[3])]
+        traces = np.ascontiguousarray(np.concatenate(given) if given else np.zeros(1, dtype=np.int32), dtype=np.int32)
+        self._h = _vp()
+        check(lib().bild_run_create(self.n_traj, iptr(Ts), self.n, aptr(trans), ctypes.addressof(st), len(per_k), dptr(logp0),
+                                    dptr(logprior), dptr(n_total), aptr(n_traces), iptr(traces), ctypes.byref(self._h)))
+        self._counts = np.zeros(8, dtype=np.int64)
+
+    def __del__(self):
+        h, self._h = getattr(self, '_h', None), None
+        if h:
+            try:
+                lib().bild_run_destroy(h)
+            except Exception:  # pragma: no cover  (interpreter shutdown)
+                pass
+
+    def _check(self, code):
+        if code != OK:
+            msg = lib().bild_run_error(self._h).decode() or lib().bild_last_error().decode()
+            raise (NoDeviceError if code == ERR_NO_DEVICE else BildAmdError)(code, msg)
+
+    def plan(self):
+        """
+        plan the next round -> (counts, shapes): counts = (gammas, uniforms, normals, rows, trajectories running, AMIS steps,
+        trajectories failed so far),
+        shapes = the gamma shape parameters (a view of the driver's buffer, valid until the next call)
+        """
+        ptr = _vp()
+        self._check(lib().bild_run_plan(self._h, aptr(self._counts), ctypes.byref(ptr)))
+        n = int(self._counts[0])
+        shapes = np.frombuffer((ctypes.c_double * n).from_address(ptr.value), dtype=np.float64) if n else np.empty(0)
+        return self._counts, shapes
+
+    def round(self, model, ts, gammas, uniforms, normals, path='auto'):
+        """ the planned round on the GPU: rows, ONE likelihood call over all of them, bookkeeping (bild_run_round) """
+        self._check(lib().bild_run_round(self._h, model._h, ts._h, PATHS[path], dptr(gammas), dptr(uniforms), dptr(normals)))
+
+    def stage(self, gammas, uniforms):
+        """ -> (ss (n, K1), thetas (n, K1) int64, traj_id (n,)): the round's candidate rows, for a caller that evaluates them itself """
+        self._check(lib().bild_run_stage(self._h, dptr(gammas), dptr(uniforms)))
+        n, K1 = ctypes.c_int64(0), ctypes.c_int(0)
+        p_ss, p_th, p_id = _vp(), _vp(), _vp()
+        self._check(lib().bild_run_rows(self._h, ctypes.byref(n), ctypes.byref(K1), ctypes.byref(p_ss), ctypes.byref(p_th), ctypes.byref(p_id)))
+        n, K1 = n.value, K1.value
+        if n == 0:
+            return np.empty((0, K1)), np.empty((0, K1), dtype=np.int64), np.empty(0, dtype=np.int32)
+        ss = np.frombuffer((ctypes.c_double * (n * K1)).from_address(p_ss.value), dtype=np.float64).reshape(n, K1)
+        thetas = np.frombuffer((ctypes.c_int64 * (n * K1)).from_address(p_th.value), dtype=np.int64).reshape(n, K1)
+        traj_id = np.frombuffer((ctypes.c_int32 * n).from_address(p_id.value), dtype=np.int32)
+        return ss, thetas, traj_id
+
+    def finish(self, logLs, normals):
+        logLs = f64(logLs)
+        self._check(lib().bild_run_finish(self._h, dptr(logLs), dptr(normals)))
+
+    # -- results ---------------------------------------------------------------------------------------------
+    def traj_info(self, j):
+        """ -> (state, kind of failure, samplers, log rows, width, message) """
+        info = np.zeros(5, dtype=np.int64)
+        msg = ctypes.c_char_p()
+        self._check(lib().bild_run_traj_info(self._h, j, aptr(info), ctypes.byref(msg)))
+        return int(info[0]), int(info[1]), int(info[2]), int(info[3]), int(info[4]), (msg.value or b'').decode()
+
+    def traj_log(self, j, rows, width):
+        k, flags = np.zeros(rows, dtype=np.int32), np.zeros(rows, dtype=np.int32)
+        i_la, pk, kld = np.zeros(rows), np.zeros((rows, width)), np.zeros((rows, width))
+        self._check(lib().bild_run_traj_log(self._h, j, iptr(k), iptr(flags), dptr(i_la), dptr(pk), dptr(kld)))
+        return k, flags, i_la, pk, kld
+
+    def sampler_info(self, j, k):
+        """ -> (kind, exhausted, steps, evidences, enumerated rows) """
+        info = np.zeros(5, dtype=np.int64)
+        self._check(lib().bild_run_sampler_info(self._h, j, k, aptr(info)))
+        return int(info[0]), bool(info[1]), int(info[2]), int(info[3]), int(info[4])
+
+    def sampler_data(self, j, k, n_ev, rows):
+        ev = np.zeros((n_ev, 3))
+        ss, th, logL = np.zeros((rows, k + 1)), np.zeros((rows, k + 1), dtype=np.int64), np.zeros(rows)
+        self._check(lib().bild_run_sampler_data(self._h, j, k, dptr(ev), dptr(ss), aptr(th), dptr(logL)))
+        return ev, ss, th, logL
+
+    def take_core(self, j, k):
+        h = _vp()
+        self._check(lib().bild_run_take_core(self._h, j, k, ctypes.byref(h)))
+        return _adopt_amis_core(h, self.n, k + 1) if h.value else None
+
+    def totals(self):
+        """ -> (rounds, likelihood evaluations, host threads) """
+        t = np.zeros(3, dtype=np.int64)
+        self._check(lib().bild_run_totals(self._h, aptr(t)))
+        return int(t[0]), int(t[1]), int(t[2])
 
 
 def choice_counts(rvs, mu, dmu, dE, omit=None, want_dn=True):

@@ -496,6 +496,56 @@ class FixedkSampler:
         except FixedkSampler.ExhaustionImpractical:
             pass
 
+    @classmethod
+    def _adopt_native(cls, traj, model, k, settings, shared, info, data, core):
+        """
+        A sampler whose whole history was produced by the inference driver (csrc/run_host.cpp, `core.sample_many`): the same
+        object `__init__` + `step()` calls would have left behind, built without repeating any of their work.  The native
+        bookkeeping (proposals, pooled samples and their arrays) is adopted as it is and fetched when somebody looks.
+
+        settings : the sampler keywords of the run; shared : (Dirichlet, CFC, logprior) of this k;
+        info : (kind, exhausted, steps, ...) from `RunHandle.sampler_info`; data : (evidences, ss, thetas, logLs);
+        core : the adopted `_lib.AmisCore` or None.
+        """
+        self = object.__new__(cls)
+        kind, exhausted, steps = info[0], info[1], info[2]
+        evidences, ss, thetas, logLs = data
+        self.k, self.N, self.native, self.fused, self.rng = k, settings['N'], True, True, 'numpy'
+        self.seed = int.from_bytes(os.urandom(8), 'little')
+        self._device_drawn, self._adopted, self.device_bookkeeping = 0, core is not None, None
+        self.brakes = (settings['concentration_brake'], settings['polarization_brake'])
+        self.max_fev, self.max_fcomplete = settings['max_fev'], settings['max_fcomplete']
+        self.exhausted, self.traj, self.model = exhausted, traj, model
+        self.evidences = [tuple(row) for row in evidences]
+        if kind == 0:       # k >= T (bild/amis.py:641-648): nothing else exists
+            return self
+        self.dirichlet, self.cfc, self.logprior = shared
+        self._sizes = [settings['N']] * steps if kind == 2 else [len(logLs)]
+        self._pool_np = {'ss': ss, 'thetas': thetas} if kind == 1 else None
+        self._chunks = []
+        self._arr_np = {'logLs': logLs} if kind == 1 else {}
+        self._arr_cache = (None, None)
+        self.samples = _SampleList(self)
+        self._core = core
+        self._parameters = None if core is not None else [(np.ones(k + 1), self.cfc.logp_uniform(k))]
+        self._As = np.empty((0, k + 1))
+        self._heads = np.empty((0, self.cfc.n))
+        self._tables = np.empty((0, k * self.cfc.n ** 2))
+        return self
+
+    @property
+    def parameters(self):
+        """ the proposals used so far, [(a, logp), ...] (bild/amis.py:650-653); an adopted sampler fetches them when asked """
+        if self._parameters is None:
+            from . import _lib
+            Q = int(_lib.lib().bild_amis_num_proposals(self._core._h))
+            self._parameters = [self._core.params(q) for q in range(Q)]
+        return self._parameters
+
+    @parameters.setter
+    def parameters(self, value):
+        self._parameters = value
+
     def _new_core(self, on_device=None):
         from . import _lib
         self._core = _lib.AmisCore(self.model.transitions, self.parameters[0][0], self.parameters[0][1],
@@ -515,7 +565,9 @@ class FixedkSampler:
 
     # -- pickling / copying: the native core is rebuilt from the pooled arrays ---------------------------
     def __getstate__(self):
-        self._pool                                    # append pending chunks
+        if 'dirichlet' in self.__dict__:              # (a sampler with k >= T holds nothing)
+            self._pool                                # append pending chunks
+            self.parameters                           # (an adopted sampler: fetch them)
         state = dict(self.__dict__)
         if state.get('_core') is not None:
             state['_arr_np'] = dict(self._arr)
@@ -525,12 +577,16 @@ class FixedkSampler:
 
     def __setstate__(self, state):
         had_core = state.get('_core')
+        if 'parameters' in state:       # (pickles written before `parameters` became a property)
+            state = dict(state)
+            state['_parameters'] = state.pop('parameters')
         self.__dict__.update(state)
         if had_core is not None and '_core' in state:
             self.samples = _SampleList(self)
             self._core = self._new_core(on_device=False)
             if had_core:
-                self._core.restore(self.parameters[1:], self._pool['ss'], self._pool['thetas'], self._arr_np)
+                # (`_pool_np` itself, not the property: that one would ask the new, still empty core for the samples)
+                self._core.restore(self.parameters[1:], self._pool_np['ss'], self._pool_np['thetas'], self._arr_np)
             self._place_core()
         elif 'samples' in state:
             self.samples = _SampleList(self)
@@ -538,9 +594,11 @@ class FixedkSampler:
     @property
     def _pool(self):
         """ pooled samples ('ss', 'thetas' [, lookup data of the NumPy path]); pending chunks are appended on access """
-        if getattr(self, '_device_drawn', 0) and (self._pool_np is None or len(self._pool_np['ss']) != len(self._core)):
-            ss, thetas = self._core.pool_samples()      # drawn on the device: fetched now
+        if ((getattr(self, '_device_drawn', 0) or getattr(self, '_adopted', False)) and self._core is not None
+                and (self._pool_np is None or len(self._pool_np['ss']) + sum(len(c[0]) for c in self._chunks) != len(self._core))):
+            ss, thetas = self._core.pool_samples()      # drawn on the device / by the inference driver: fetched now
             self._pool_np = {'ss': ss, 'thetas': thetas}
+            self._chunks = []
             return self._pool_np
         if self._chunks:
             parts_ss = ([self._pool_np['ss']] if self._pool_np else []) + [c[0] for c in self._chunks]

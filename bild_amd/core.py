@@ -142,22 +142,187 @@ class _AdaptiveRun:
         self.progress.close()
 
 
-def sample_many(trajs, model, **kwargs):
+def sample_many(trajs, model, driver='auto', return_exceptions=False, **kwargs):
     """
-    `sample` for a list of trajectories, run concurrently; the AMIS batches that are pending at
-    the same time are evaluated together in one launch per round (see `batching`).
+    `sample` for a list of trajectories, run concurrently: one ROUND advances the adaptive-k loop of every trajectory
+    by one iteration, and all candidate profiles of a round are evaluated in ONE likelihood call.
+
+    ``driver='native'`` (what ``'auto'`` picks whenever it applies): the loops run inside the native inference driver
+    (csrc/run_host.cpp, `_lib.RunHandle`) -- Python is touched once per round, for three bulk draws from the global NumPy
+    stream (``standard_gamma``, ``random_sample``, ``standard_normal``), not once per sampler step.  Per trajectory the
+    random numbers are consumed in the reference's order, so ``sample_many([traj], model)`` walks through the same random
+    numbers as ``sample(traj, model)`` and gives the same result bit for bit; with several trajectories the stream is
+    shared round by round (every run is a valid run of `sample`, none is the one a sequential call would have made).
+    It applies to the default keywords of `sample` and to ``sampler_kw`` within {N (< 2000), concentration_brake,
+    polarization_brake, max_fev, max_fcomplete}, ``choice_kw`` within {samplesize}, and to models that are a plain
+    `MultiStateRouse` (GPU likelihood) or offer ``logL_segments(seg_start, seg_state, trajs, traj_id)``.
+    ``driver='python'``: one unmodified `sample` loop per trajectory as cooperative tasks whose pending AMIS batches are
+    fused into one launch (`batching.run_batched`; any keyword `sample` takes).
 
     Returns a list of `SamplingResults`, one per trajectory, in order.  With ``return_exceptions=True``
     a trajectory whose loop raised gets the exception object as its entry instead of aborting the rest.
     """
+    if driver not in ('auto', 'native', 'python'):
+        raise ValueError("driver must be 'auto', 'native' or 'python'")
+    trajs = list(trajs)
+    if driver != 'python':
+        plan, why = _native_plan(model, kwargs)
+        if plan is not None:
+            return _sample_many_native(trajs, model, return_exceptions, plan)
+        if driver == 'native':
+            raise ValueError("the native inference driver does not apply: " + why)
     from .batching import run_batched
-    results = run_batched(trajs, model, sample, **kwargs)
+    results = run_batched(trajs, model, sample, return_exceptions=return_exceptions, **kwargs)
     for res in results:     # the loops saw a batching proxy of the model: hand the real one back
         if isinstance(res, SamplingResults):
             res.model = model
             for sampler in res.samplers:
                 sampler.model = model
     return results
+
+
+_SAMPLE_DEFAULTS = dict(dE=0, init_runs=20, certainty_in_k=0.99, k_lookahead=2, k_max=20, sampler_kw={}, choice_kw={}, show_progress=False)
+_SAMPLER_DEFAULTS = dict(N=100, concentration_brake=1e-2, polarization_brake=1e-3, max_fev=20000, max_fcomplete=1000)
+_per_k_cache = {}
+
+
+def _native_plan(model, kwargs):
+    """ (settings for the native driver, None) when it can run this call, else (None, the reason) """
+    from .models import MultiStateRouse
+    unknown = set(kwargs) - set(_SAMPLE_DEFAULTS)
+    if unknown:
+        return None, f"unknown keywords {sorted(unknown)}"
+    kw = dict(_SAMPLE_DEFAULTS, **kwargs)
+    sampler_kw, choice_kw = dict(kw['sampler_kw']), dict(kw['choice_kw'])
+    if kw['show_progress']:
+        return None, "show_progress"
+    if set(sampler_kw) - set(_SAMPLER_DEFAULTS):
+        return None, f"sampler_kw {sorted(set(sampler_kw) - set(_SAMPLER_DEFAULTS))}"
+    if set(choice_kw) - {'samplesize'}:
+        return None, f"choice_kw {sorted(set(choice_kw) - {'samplesize'})}"
+    smp = dict(_SAMPLER_DEFAULTS, **sampler_kw)
+    if smp['N'] >= 2000:
+        return None, "N >= 2000 per step (the fused device step of `FixedkSampler` serves such batches)"
+    if type(model) is MultiStateRouse:
+        mode = 'gpu'
+    elif hasattr(model, 'logL_segments'):
+        mode = 'segments'
+    else:
+        return None, "the model offers no batch entry over several trajectories"
+    if not all(float(v).is_integer() and v >= 0 for v in (kw['init_runs'], kw['k_lookahead'], kw['k_max'], smp['N'], smp['max_fev'],
+                                                            smp['max_fcomplete'], choice_kw.get('samplesize', 10000))) or smp['N'] < 1:
+        return None, "non-integer settings"
+    return dict(mode=mode, dE=float(kw['dE']), init_runs=int(kw['init_runs']), certainty_in_k=float(kw['certainty_in_k']),
+                k_lookahead=int(kw['k_lookahead']), k_max=int(kw['k_max']), samplesize=int(choice_kw.get('samplesize', 10000)),
+                sampler=dict(N=int(smp['N']), concentration_brake=float(smp['concentration_brake']),
+                             polarization_brake=float(smp['polarization_brake']), max_fev=int(smp['max_fev']),
+                             max_fcomplete=int(smp['max_fcomplete']))), None
+
+
+def _per_k_constants(transitions, k_max, Nmax):
+    """
+    what `FixedkSampler.__init__` derives from (transitions, k) alone, for k = 0 .. k_max: the uniform CFC weights, the
+    log-prior of a profile, the number of valid traces and -- where they may be enumerated -- the traces themselves
+    (bild/amis.py:650-659, 776).  Cached per transition matrix: twenty milliseconds of exact integer path counting.
+    """
+    from .amis import CFC, Dirichlet
+    transitions = np.asarray(transitions, dtype=bool)
+    key = (transitions.shape[0], transitions.tobytes())
+    hit = _per_k_cache.setdefault(key, {'cfc': CFC(transitions), 'dirichlet': Dirichlet(), 'k': {}})
+    cfc, out = hit['cfc'], []
+    for k in range(k_max + 1):
+        if k not in hit['k']:
+            n_total = cfc.N_total(k)
+            hit['k'][k] = (cfc.logp_uniform(k), float(np.sum(np.log(np.arange(k) + 1))) - cfc.N_total(k, log=True), n_total, {})
+        logp0, logprior, n_total, traces = hit['k'][k]
+        tr = None
+        if n_total <= Nmax:
+            if 'all' not in traces:
+                traces['all'] = cfc.full_sample(k, Nmax=n_total)
+            tr = traces['all']
+        out.append((logp0, logprior, float(min(n_total, 10 ** 300)), tr))
+    return hit, out
+
+
+def _sample_many_native(trajs, model, return_exceptions, plan):
+    """ `sample_many` through the native inference driver (see there) """
+    from . import _lib
+    from .amis import FixedkSampler
+    trajs = [make_trajectory(t) for t in trajs]
+    if not trajs:
+        return []
+    smp = plan['sampler']
+    shared, per_k = _per_k_constants(model.transitions, plan['k_max'], min(smp['max_fcomplete'], smp['max_fev']))
+    settings = dict(init_runs=plan['init_runs'], k_lookahead=plan['k_lookahead'], k_max=plan['k_max'], reserved=0,
+                    certainty_in_k=plan['certainty_in_k'], dE=plan['dE'], N=smp['N'], concentration_brake=smp['concentration_brake'],
+                    polarization_brake=smp['polarization_brake'], max_fev=smp['max_fev'], max_fcomplete=smp['max_fcomplete'],
+                    choice_samplesize=plan['samplesize'])
+    lengths = [len(t) for t in trajs]
+    run = _lib.RunHandle(lengths, model.transitions, settings, per_k)
+    gpu = plan['mode'] == 'gpu'
+    if gpu:
+        handle, ts = model.handle(), model.trajset(trajs)
+    else:
+        T_arr, n_states = np.asarray(lengths, dtype=np.int32), int(model.nStates)
+    def raise_first_failure():      # a loop that raised ends the call, as an exception out of `sample` would
+        for j in range(len(trajs)):
+            info = run.traj_info(j)
+            if info[0] == 2:
+                raise _native_error(info)
+
+    failed_before = 0
+    while True:
+        counts, shapes = run.plan()
+        n_gamma, n_uniform, n_normal, n_rows, live = (int(v) for v in counts[:5])
+        if not return_exceptions and int(counts[6]) > failed_before:
+            raise_first_failure()
+        if n_rows == 0 and live == 0:
+            break
+        # the round's random numbers: three bulk draws from the global NumPy stream
+        gammas = np.random.standard_gamma(shapes) if n_gamma else np.empty(0)
+        uniforms = np.random.random_sample(n_uniform)
+        normals = np.random.standard_normal(n_normal)
+        if gpu:
+            run.round(handle, ts, gammas, uniforms, normals, path=model.path)
+        else:
+            ss, thetas, tid = run.stage(gammas, uniforms)
+            if len(tid):
+                seg_start, seg_state = _lib.segments_from_st(ss, thetas, T_arr[tid], n_states)
+                logLs = np.asarray(model.logL_segments(seg_start, seg_state, trajs, tid), dtype=np.float64)
+            else:
+                logLs = np.empty(0)
+            run.finish(logLs, normals)
+    results = []
+    for j, traj in enumerate(trajs):
+        state, kind, n_samplers, n_rows, width, message = run.traj_info(j)
+        if state == 2:
+            results.append(_native_error((state, kind, n_samplers, n_rows, width, message)))
+            continue
+        samplers = []
+        for k in range(n_samplers):
+            info = run.sampler_info(j, k)
+            data = run.sampler_data(j, k, info[3], info[4])
+            core = run.take_core(j, k) if info[0] == 2 else None
+            samplers.append(FixedkSampler._adopt_native(traj, model, k, smp, (shared['dirichlet'], shared['cfc'], per_k[k][1]) if k < len(per_k) else None,
+                                                        info, data, core))
+        ks, flags, i_la, pk, kld = run.traj_log(j, n_rows, width)
+        flags = flags.tolist()
+        log = {'k': ks.tolist(),
+               'pk': [pk[i, :(f >> 8) & 255] if f & 1 else None for i, f in enumerate(flags)],
+               'KLD': [kld[i, :(f >> 16) & 255] if f & 2 else None for i, f in enumerate(flags)],
+               'I_la': [float(i_la[i]) if f & 4 else None for i, f in enumerate(flags)]}
+        results.append(SamplingResults(traj, model, plan['dE'], samplers, log))
+    return results
+
+
+def _native_error(info):
+    kind, message = info[1], info[5]
+    if kind == 1:
+        return RuntimeError(message)
+    if kind == 2:
+        return ValueError(message)
+    from . import _lib
+    return _lib.BildAmdError(1, message)
 
 
 class _NoBar:

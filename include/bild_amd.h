@@ -442,6 +442,82 @@ int bild_choice_counts(int64_t samplesize, int kmax, const double *rvs, const do
                        const double *dmu, double dE, const uint8_t *omit,
                        int64_t *n0, int64_t *dn, int64_t *n_omit);
 
+/* ------------------------------------------------ the inference driver ------------
+ * the adaptive-k loops of bild.core.sample (bild/core.py:138-227) for MANY trajectories
+ * as one native state machine, advanced one ROUND at a time.  A round is one iteration of that loop for every trajectory
+ * that is still running: at most one AMIS step (bild/amis.py:805-906) per trajectory, the exhaustive enumerations of the
+ * samplers it opens (bild/amis.py:741-803), the choice sampler that picks the next k (bild/choicesampler.py:83-210) and
+ * the stop rules -- with ONE likelihood call for all candidate rows of the round, and the per-trajectory bookkeeping on a
+ * pool of host threads (BILD_HOST_THREADS, default min(8, cores)).
+ *
+ * Random numbers are NOT drawn by the library: bild_run_plan says how many the round needs, the caller draws them in
+ * bulk from whatever stream it keeps (bild_amd.core.sample_many: three vectorised NumPy calls per round) --
+ *     gammas    counts[0] standard gamma variates with the shape parameters *gamma_shapes  (np.random.standard_gamma)
+ *     uniforms  counts[1] numbers in [0, 1)                                                  (np.random.random_sample)
+ *     normals   counts[2] standard normal numbers                                            (np.random.standard_normal)
+ * and per trajectory they are consumed in the reference's order: the gamma variates of the Dirichlet draw (normalised
+ * exactly as np.random.dirichlet does: sequential sum, one reciprocal), the uniforms of the state traces (k + 1 blocks
+ * of N, bild_amis_sample_traces), the samplesize x kmax normals of the choice sampler.  A run of ONE trajectory therefore
+ * walks through the random numbers bild.core.sample would and reproduces it bit for bit.
+ *
+ * Per-k constants that do not depend on the trajectory are the caller's to provide, for k = 0 .. n_k - 1 (n_k >= k_max + 1):
+ *     logp0     the CFC weights of the uniform distribution over traces (CFC.logp_uniform, amis.py:455-476),
+ *               concatenated: n_states x (k + 1) doubles for each k
+ *     logprior  log k! - log N_total(k)                                  (amis.py:654-659)
+ *     n_total   N_total(k), the number of valid traces                   (amis.py:478-497)
+ *     n_traces / traces   for every k that may be enumerated: all valid traces (CFC.full_sample, amis.py:499-536),
+ *               n_traces[k] x (k + 1) int32, concatenated over k; n_traces[k] = 0: none given
+ */
+typedef struct bild_run bild_run;
+typedef struct bild_run_settings {
+    int32_t init_runs;            /* AMIS steps a freshly opened sampler takes at once (core.py:24: 20)   */
+    int32_t k_lookahead;          /* core.py:26: 2                                                          */
+    int32_t k_max;                /* core.py:27: 20                                                         */
+    int32_t reserved;
+    double  certainty_in_k;       /* stop when max p(k) reaches it (core.py:25: 0.99)                      */
+    double  dE;                   /* evidence margin (core.py:23: 0)                                        */
+    int64_t N;                    /* candidates per AMIS step (amis.py:624: 100)                            */
+    double  concentration_brake;  /* amis.py:625: 1e-2                                                      */
+    double  polarization_brake;   /* amis.py:626: 1e-3                                                      */
+    int64_t max_fev;              /* amis.py:627: 20000                                                     */
+    int64_t max_fcomplete;        /* amis.py:628: 1000                                                      */
+    int64_t choice_samplesize;    /* choicesampler.py:83: 10000                                             */
+} bild_run_settings;
+int bild_run_create(int n_traj, const int32_t *T, int n_states, const uint8_t *transitions,
+                    const bild_run_settings *settings, int n_k, const double *logp0, const double *logprior,
+                    const double *n_total, const int64_t *n_traces, const int32_t *traces, bild_run **out);
+int bild_run_destroy(bild_run *r);
+const char *bild_run_error(const bild_run *r);
+/* counts[8]: gammas, uniforms, normals, candidate rows of the round, trajectories still running, AMIS steps in the round,
+ * trajectories that have failed so far (bild_run_traj_info), reserved.
+ * counts[3] == 0 and counts[4] == 0: the run is over (no stage / finish for this plan). */
+int bild_run_plan(bild_run *r, int64_t *counts, const double **gamma_shapes);
+/* the whole round on the GPU: rows from the random numbers, bild_logl_st over them (traj_id = index of the trajectory in
+ * the set `ts`, which must hold the run's trajectories in order), bookkeeping */
+int bild_run_round(bild_run *r, const bild_model *m, const bild_trajset *ts, unsigned flags,
+                   const double *gammas, const double *uniforms, const double *normals);
+/* the same in three steps for a caller that evaluates the rows itself (CPU tests, models that are not this library's):
+ * stage, look at the rows (ss: n x K1 float64, thetas: n x K1 int64, traj_id: n; rows shorter than K1 are padded with
+ * empty intervals in their last state), finish with their log-likelihoods */
+int bild_run_stage(bild_run *r, const double *gammas, const double *uniforms);
+int bild_run_rows(const bild_run *r, int64_t *n, int *K1, const double **ss, const int64_t **thetas,
+                  const int32_t **traj_id);
+int bild_run_finish(bild_run *r, const double *logLs, const double *normals);
+/* results.  traj_info: info[5] = state (0 running, 1 done, 2 failed), kind of failure (1: "Iteration did not converge",
+ * a RuntimeError in the reference; 2: ValueError; 3: other), samplers, log rows, widest pk / KLD row.
+ * traj_log: k, flags (bit 0: pk given, 1: KLD given, 2: I_la given; bits 8-15 / 16-23: entries of the pk / KLD row), I_la,
+ * pk and KLD (rows x width, NaN-padded).
+ * sampler_info: info[5] = kind (0: k >= T, 1: enumerated, 2: AMIS), exhausted, AMIS steps, evidences, enumerated rows.
+ * sampler_data: evidences (x 3); for an enumerated sampler its rows.  take_core: ownership of an AMIS sampler's native
+ * bookkeeping passes to the caller (bild_amis_destroy).  totals[3]: rounds, likelihood evaluations, host threads. */
+int bild_run_traj_info(const bild_run *r, int j, int64_t *info, const char **message);
+int bild_run_traj_log(const bild_run *r, int j, int32_t *k, int32_t *flags, double *i_la, double *pk, double *kld);
+int bild_run_sampler_info(const bild_run *r, int j, int k, int64_t *info);
+int bild_run_sampler_data(const bild_run *r, int j, int k, double *evidences, double *ss, int64_t *thetas,
+                          double *logLs);
+int bild_run_take_core(bild_run *r, int j, int k, bild_amis **out);
+int bild_run_totals(const bild_run *r, int64_t *totals);
+
 /* Weighted state occupancy per frame over a set of profiles (reference bild/amis.py:945-972):
  * post[s*T + t] = sum of w[p] over the profiles p that are in state s at frame t.  Profiles as
  * in bild_logl_segments (P x k1).  Sums of non-negative terms only. */

@@ -284,8 +284,8 @@ def test_device_rng_streams_survive_pickling_and_differ_between_k(built_lib):
     and the samplers of one adaptive-k run, which share the user's seed, must not share streams.
     """
     import copy
-    import pickle
     import bild_amd
+    import helpers as H
     rng = np.random.default_rng(21)
     model = bild_amd.MultiStateRouse(20, 1, 5, d=3, localization_error=0.1)
     traj = model.trajectory_from_loopingprofile(H.random_profile(rng, 300, 2, 60), rng=rng)
