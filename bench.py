@@ -648,22 +648,38 @@ def main():
             trajs4 = [model4.trajectory_from_loopingprofile(H.random_profile(rng4, int(rng4.integers(150, 601)), 2, 120), rng=rng4)
                       for _ in range(64)]
             model4.logL_segments(np.zeros((1, 1), np.int32), np.zeros((1, 1), np.int32), trajs4, np.zeros(1, np.int32))   # upload
+
+            def run4(**kw4):
+                _lib.kernel_timing(True)
+                t0 = time.perf_counter()
+                res = bild_amd.sample_many(trajs4, model4, return_exceptions=True, **kw4)
+                wall = time.perf_counter() - t0
+                _lib.kernel_timing(False)
+                kms, launches, _ = _lib.kernel_timing_read()
+                wms, wl = _lib.kernel_timing_read_walk()
+                ok = [r for r in res if not isinstance(r, Exception)]
+                evals = sum(len(smp['logLs']) for r in ok for s_ in r.samplers for smp in s_.samples)
+                return {'wall_s': wall, 'trajectories_done': len(ok), 'amis_steps': sum(len(r.log['k']) for r in ok),
+                        'likelihood_evaluations': evals, 'evals_per_s': evals / wall, 'gpu_busy_ms': kms + wms,
+                        'gpu_busy_share': (kms + wms) * 1e-3 / wall, 'kernel_launches': launches + wl,
+                        'best_k_histogram': np.bincount([int(r.best_k()) for r in ok]).tolist()}
             np.random.seed(11)
-            _lib.kernel_timing(True)
-            t0 = time.perf_counter()
-            res4 = bild_amd.sample_many(trajs4, model4, return_exceptions=True)
-            wall4 = time.perf_counter() - t0
-            _lib.kernel_timing(False)
-            kms4, launches4, _ = _lib.kernel_timing_read()
-            wms4, wl4 = _lib.kernel_timing_read_walk()
-            ok4 = [r for r in res4 if not isinstance(r, Exception)]
-            evals4 = sum(len(smp['logLs']) for r in ok4 for s_ in r.samplers for smp in s_.samples)
+            run4()                                  # (the per-k constants of the transition matrix, cached per process: 10 ms)
+            np.random.seed(11)
+            c4 = run4()
+            c4_gen = run4(rng=np.random.default_rng(11))
+            np.random.seed(11)
+            c4_py = run4(driver='python')
             result['config4'] = {
                 'what': 'BASELINE configs[4]: bild.core.sample with default settings (adaptive k, N = 100 per AMIS step) on 64 synthetic '
-                        'trajectories of T ~ U{150..600}, fused across trajectories by sample_many; one GPU',
-                'wall_s': wall4, 'trajectories_done': len(ok4), 'likelihood_evaluations': evals4, 'evals_per_s': evals4 / wall4,
-                'gpu_busy_ms': kms4 + wms4, 'gpu_busy_share': (kms4 + wms4) * 1e-3 / wall4, 'kernel_launches': launches4 + wl4,
-                'best_k_histogram': np.bincount([int(r.best_k()) for r in ok4]).tolist()}
+                        'trajectories of T ~ U{150..600} through sample_many: the native inference driver (csrc/run_host.cpp) -- one '
+                        'round = one likelihood call over the pending candidates of ALL trajectories + their bookkeeping on host '
+                        'threads; random numbers from the global NumPy stream (the reference\'s), three bulk draws per round; one GPU',
+                **c4,
+                'with_numpy_generator': dict(c4_gen, what='the same with rng=np.random.default_rng(11): the three bulk draws per round through '
+                                                          'a numpy Generator instead of the legacy global stream'),
+                'python_driver': dict(c4_py, what="driver='python': round 3's way -- one Python loop per trajectory as cooperative "
+                                                  "tasks, pending batches fused into one launch")}
             del model4
         except Exception as exc:
             result['config4'] = {'error': repr(exc)}

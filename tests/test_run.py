@@ -236,3 +236,18 @@ def test_driver_selection_and_errors():
     assert counts[3] > 0
     with pytest.raises(_lib.BildAmdError, match="not been finished"):
         run.plan()
+
+
+def test_a_numpy_generator_as_the_source_of_random_numbers():
+    tables, trajs = _problem(4, seed=85)
+    model = RoutedTables(tables)
+    kw = dict(init_runs=3, k_max=4, sampler_kw={'N': 20, 'max_fev': 200, 'max_fcomplete': 30}, choice_kw={'samplesize': 500})
+    state = np.random.get_state()[1].copy()
+    a = bild_amd.sample_many(trajs, model, rng=np.random.default_rng(3), **kw)
+    b = bild_amd.sample_many(trajs, model, rng=np.random.default_rng(3), **kw)
+    assert np.array_equal(np.random.get_state()[1], state)         # the global stream was not touched
+    for x, y in zip(a, b):
+        _same_result(x, y)
+    assert all(np.all(np.isfinite(r.evidence[:2])) for r in a)
+    with pytest.raises(ValueError, match="native inference driver only"):
+        bild_amd.sample_many(trajs, model, driver='python', rng=np.random.default_rng(3), **kw)
