@@ -173,6 +173,8 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--repeats', type=int, default=60, help='timed regions of exactly --steps steps; the median one is reported')
+    ap.add_argument('--sustained', type=float, default=4.0, help='seconds of back-to-back steps for the `sustained` figure (0: skip)')
     ap.add_argument('--samples', type=int, default=10000, help='candidate profiles per GPU per step (weak scaling)')
     ap.add_argument('--T', type=int, default=1000)
     ap.add_argument('--k', type=int, default=4)
@@ -295,37 +297,69 @@ def main():
             else:
                 d_all.copy_(bdist.all_gather_logl(d_out.cpu()))
 
-    def timed(fn, steps, warmup, sample=4, handle=None):
-        # (kernel durations from HIP events around every `sample`-th launch of the timed region: the events cost a few
+    def timed(fn, steps, warmup, sample=4, handle=None, repeats=1):
+        # The timed region -- EXACTLY `steps` steps between barrier + synchronize on both sides, maximum over ranks -- is run
+        # `repeats` times and the MEDIAN region is what is reported: one region of a latency-bound launch is a millisecond
+        # long and scatters by +-5 % from run to run (round 3: 168.6 M in the driver's run, 172-178 M in the builder's).
+        # (kernel durations from HIP events around every `sample`-th launch of the timed regions: the events cost a few
         # microseconds per launch, which every step would otherwise pay)
         for _ in range(warmup):
             fn()
         coll_events.clear()
         _lib.kernel_timing(sample if steps >= 2 * sample else 1)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            fn()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        dt = time.perf_counter() - t0
+        dts = []
+        for _ in range(repeats):
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            dts.append(time.perf_counter() - t0)
         _lib.kernel_timing(False)
         kms, launches, kname = _lib.kernel_timing_read()
         wms, wl = _lib.kernel_timing_read_walk()
         timed.frames_per_launch = _lib.frames_run_read(handle or h) / max(launches, 1)   # counted on the device by the tasks themselves
         timed.walk_ms = wms / max(wl, 1)
-        timed.local_dt = dt
+        dts = np.array(dts)
+        timed.local_dt = float(np.median(dts))
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == 'nccl' else 'cpu')
+            t = torch.from_numpy(dts).to(dev if args.backend == 'nccl' else 'cpu')
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt, kms / max(launches, 1), kname
+            dts = t.cpu().numpy()
+        q25, med, q75 = (float(v) for v in np.percentile(dts, [25, 50, 75]))
+        per = 1e3 / steps
+        timed.stats = {'repeats': int(repeats), 'median': med * per, 'q25': q25 * per, 'q75': q75 * per, 'iqr': (q75 - q25) * per,
+                       'min': float(dts.min()) * per, 'max': float(dts.max()) * per, 'timed_region_s': float(dts.sum()),
+                       'what': f'ms per step over {repeats} timed regions of exactly {steps} steps each (barrier + synchronize on both '
+                               'sides, maximum over ranks per region); `value` and `ms_per_step` are the median region'}
+        return med, kms / max(launches, 1), kname
 
-    dt, kernel_ms, kname = timed(step, args.steps, args.warmup)
+    def sustained(fn, seconds, per_step_s, chunk=512):
+        """
+        back-to-back steps for about `seconds` (one synchronisation per `chunk` steps): -> (steps per second, wall).  The number
+        of steps is fixed beforehand from the measured step time (the same on every rank: the steps hold a collective)
+        """
+        chunks = max(1, int(np.ceil(seconds / max(per_step_s, 1e-6) / chunk)))
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(chunks):
+            for _ in range(chunk):
+                fn()
+            torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        wall = time.perf_counter() - t0
+        return chunks * chunk / wall, wall
+
+    dt, kernel_ms, kname = timed(step, args.steps, args.warmup, repeats=args.repeats)
     walk_ms = timed.walk_ms
+    headline_stats = timed.stats
     value = n_global * args.steps / dt
     frames_total = float(sum(len(trajs[j]) for j in (traj_id if traj_id is not None else np.zeros(n, dtype=int))))
     frames_frac = timed.frames_per_launch / frames_total
@@ -397,6 +431,7 @@ def main():
         'metric': 'logL evaluations/sec (T=1000, 2-state) per AMIS batch',
         'value': value, 'unit': 'evals/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': args.scaling,
+        'ms_per_step_stats': headline_stats, 'timed_region_s': headline_stats['timed_region_s'],
         'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'config': {'workload': workload, 'samples_this_rank': n, 'samples_global': n_global, 'T': T, 'k': k,
                    'states': args.states, 'path': args.path,
@@ -405,6 +440,11 @@ def main():
         'roofline': roofline,
     }
 
+    if args.sustained > 0:
+        rate, wall_s = sustained(step, args.sustained, dt / args.steps)
+        result['sustained'] = {'what': 'back-to-back steps for at least %.0f s, one synchronisation per 512 steps (no barrier inside: every '
+                                       'rank runs its own loop)' % args.sustained,
+                               'value': n_global * rate, 'unit': 'evals/s', 'ms_per_step': 1e3 / rate, 'wall_s': wall_s}
     if world > 1:
         # ---- what a scaling run needs to explain itself -----------------------------------------------------------------
         coll_ms = float(np.mean([a.elapsed_time(b) for a, b in coll_events])) if coll_events else None
@@ -444,13 +484,17 @@ def main():
             sturn[0] += 1
             return sampler.logL(ss_, th_)
         got = sampler.logL(*seam_batches[0])
-        sdt, skms, _ = timed(seam_step, args.steps, min(args.warmup, 3))
+        sdt, skms, _ = timed(seam_step, args.steps, min(args.warmup, 3), repeats=args.repeats)
         result['api_seam'] = {
             'what': 'FixedkSampler.logL(ss, thetas): host (N,k+1) float64 + int64 in, host (N,) float64 out, per step '
                     '(bild/amis.py:717-739); the rows go up as they are (float64 + one byte per state) and are converted on the device',
             'value': (n_global if args.scaling == 'strong' else n * world) * args.steps / sdt, 'unit': 'evals/s',
             'ms_per_call': sdt / args.steps * 1e3, 'kernel_ms': skms, 'walk_kernel_ms': timed.walk_ms,
+            'ms_per_call_stats': timed.stats,
         }
+        if args.sustained > 0 and world == 1:
+            rate, wall_s = sustained(seam_step, args.sustained / 2, sdt / args.steps)
+            result['api_seam']['sustained'] = {'value': n * rate, 'unit': 'evals/s', 'ms_per_call': 1e3 / rate, 'wall_s': wall_s}
         if not (world > 1 and args.scaling == 'strong'):
             turn[0] = 0
             step()
