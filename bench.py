@@ -646,7 +646,10 @@ def main():
                         'traj_id resident in HBM',
                 'value': n_traj2 * per2 / per, 'unit': 'evals/s', 'ms_per_step': per * 1e3, 'frame_loop_kernel_ms': kms_,
                 'walk_kernel_ms': wms_, 'frames_executed_fraction': fr_ / (n_traj2 * per2 * T),
-                'tables_bytes': b2, 'tables_build_ms_device': ms2, 'upload_and_first_evaluation_s': build_s}
+                'tables_bytes': b2, 'tables_build_ms_device': ms2, 'upload_and_first_evaluation_s': build_s,
+                'tables_note': 'prefix + transient + pair tables; the transient STATE table (26 GB for this set, 0.8 s to allocate and '
+                               'fill) is built for sets of up to 4 GB of it only, unless the caller declares >= 1e8 evaluations '
+                               '(bild_trajset_expect) or sets BILD_STATES_MAX_BYTES'}
             del d1, d2, d3, ts_2, model2
         except Exception as exc:   # (a side measurement must not take the headline down with it)
             result['config2_one_gpu'] = {'error': repr(exc)}
@@ -663,8 +666,13 @@ def main():
                     miss = np.union1d(miss, [0])                      # frame 0 missing in half of them
                 trajs3.append(model3.trajectory_from_loopingprofile(H.random_profile(rng3, T3, 3, T3 // 5), missing_frames=miss, rng=rng3))
             tid3 = np.repeat(np.arange(len(kinds)), per3).astype(np.int32)
+            t0 = time.perf_counter()
             ts3 = model3.trajset(trajs3)
-            c3 = {}
+            ss3, th3 = H.candidate_profiles(rng3, 500, 4, 3)
+            _lib.logl_st(model3.handle(), ts3, ss3, th3, tid3[:500])
+            first3 = time.perf_counter() - t0
+            b3, ms3 = _lib.prefix_info(ts3)
+            c3 = {'tables_bytes': b3, 'tables_build_ms_device': ms3, 'upload_and_first_evaluation_s': first3}
             for kk in (4, 8):
                 ss3, th3 = H.candidate_profiles(rng3, len(kinds) * per3, kk, 3)
                 _lib.logl_st(model3.handle(), ts3, ss3[:500], th3[:500], tid3[:500])

@@ -235,7 +235,9 @@ struct bild_trajset {
     // are worth their build -- a property of the set and of that declaration, never of the call history
     mutable std::atomic<int64_t> expected_evals{-1};
     mutable double *d_strans = nullptr;   // transient state table (common.h), filled by the launch that builds the transient table
-    mutable int64_t strans_records = 0;
+    mutable int64_t strans_records = 0;   // records of the state table as built: strans_entries * sgap
+    mutable int64_t strans_entries = 0;   // (trajectory, chain, old state, new state, frame) combinations
+    mutable int sgap = kStateGap;         // records per entry: states 1 .. sgap - 1 frames behind the switch (sized when the table is built)
     mutable int trans_m_max = 0;          // longest converged transient of the single table
     mutable int trans_m_typ = 48;         // typical frames-to-convergence of the table's entries (90th percentile): the scheduler's yardstick
 };
@@ -765,38 +767,30 @@ int ensure_transients(const bild_model &m, const bild_trajset &ts, hipStream_t s
               hipMalloc((void **)&d_tab, bytes) == hipSuccess && hipMemsetAsync(d_tab, 0, bytes, st) == hipSuccess &&
               hipMemcpy(d_desc, host.data(), host.size() * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess &&
               hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
-    // the state table beside it (common.h: a chain of close switches starts at its second switch): an optimisation with a
-    // budget -- T x S (S - 1) x 64 records of ~1.1 KB per trajectory and chain, 141 MB for one 2-state trajectory of 1000 frames
+    // First launch: the entries alone.  How long transients last is not known before it has run, and the state table beside
+    // the entries (common.h: a chain of close switches starts at its second switch) needs a record for every gap a chain can
+    // START with -- gaps shorter than the first switch's transient, i.e. up to the longest converged transient of THIS set,
+    // not a compile-time 64: the default model's longest is 45 frames (141 -> ~100 MB per 1000-frame trajectory).
     double *d_states = nullptr;
-    if (ok && !config().no_states && !(ts.expected_evals >= 0 && ts.expected_evals < kExpectPairs)) {
-        const size_t sbytes = (size_t)ts.strans_records * prefix_record_doubles(m.NPm[kModal]) * sizeof(double);
-        const size_t budget = (size_t)std::max<int64_t>(config().states_max_bytes, 0);
-        if (sbytes <= budget && hipMemGetInfo(&free_b, &total_b) == hipSuccess && sbytes <= free_b / 3) {
-            if (hipMalloc((void **)&d_states, sbytes) != hipSuccess) {
-                d_states = nullptr;
-                (void)hipGetLastError();
-            }
-        }
-    }
-    if (ok) {
+    float ms_total = 0.f;
+    auto build_pass = [&](double *states) {
         ts.d_trans = d_tab; // launch_batch passes it on as the table to FILL (trans_state is still -1)
-        ts.d_strans = d_states;
+        ts.d_strans = states;
         (void)hipEventRecord(e0, st);
+        bool good;
         {
             BuildingScope scope(1);
-            ok = launch_batch(m, ts, nb, 2, d_desc, d_desc + 2 * nb, d_desc + 4 * nb, nullptr, BILD_PATH_MODAL, st, d_sink) == BILD_OK;
+            good = launch_batch(m, ts, nb, 2, d_desc, d_desc + 2 * nb, d_desc + 4 * nb, nullptr, BILD_PATH_MODAL, st, d_sink) == BILD_OK;
         }
         (void)hipEventRecord(e1, st);
-        ok = ok && hipStreamSynchronize(st) == hipSuccess;
+        good = good && hipStreamSynchronize(st) == hipSuccess;
         float ms = 0.f;
-        if (ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) ts.trans_build_ms = ms;
+        if (good && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) ms_total += ms;
         ts.d_trans = nullptr;
         ts.d_strans = nullptr;
-    }
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
-    if (d_desc) (void)hipFree(d_desc);
-    if (d_sink) (void)hipFree(d_sink);
+        return good;
+    };
+    if (ok) ok = build_pass(nullptr);
     if (ok) {
         std::vector<TransEntry> all((size_t)ts.trans_entries);
         ok = hipMemcpy(all.data(), d_tab, bytes, hipMemcpyDeviceToHost) == hipSuccess;
@@ -823,6 +817,39 @@ int ensure_transients(const bild_model &m, const bild_trajset &ts, hipStream_t s
             }
         }
     }
+    // Second launch: the same candidates once more, now leaving their states -- an optimisation with a budget.  The table
+    // costs what its allocation and its fill cost (tens of GB per second: 26 GB, 0.8 s, for the 256 trajectories of BASELINE
+    // configs[2]) and saves ~10 us per launch on the chains of close switches: worth it for sets of a few trajectories that
+    // see batch after batch (one trajectory: 2 ms against 9 us per AMIS step), not for hundreds of them.  4 GB unless the
+    // caller has declared >= 1e8 evaluations on the set (then 64 GB) or BILD_STATES_MAX_BYTES says otherwise; always at most
+    // a third of the free memory.  Which tables exist depends on the set and that declaration alone (reproducibility).
+    if (ok && !config().no_states && !(ts.expected_evals >= 0 && ts.expected_evals < kExpectPairs) && ts.trans_m_max >= 2) {
+        const int sgap = std::min<int>(kStateGap, ts.trans_m_max + 1);
+        const size_t sbytes = (size_t)ts.strans_entries * sgap * prefix_record_doubles(m.NPm[kModal]) * sizeof(double);
+        size_t budget = (size_t)std::max<int64_t>(config().states_max_bytes, 0);
+        if (config().states_max_bytes < 0) budget = ts.expected_evals >= (int64_t)100000000 ? ((size_t)64 << 30) : ((size_t)4 << 30);
+        if (sbytes <= budget && hipMemGetInfo(&free_b, &total_b) == hipSuccess && sbytes <= free_b / 3) {
+            if (hipMalloc((void **)&d_states, sbytes) != hipSuccess) {
+                d_states = nullptr;
+                (void)hipGetLastError();
+            }
+        }
+        if (d_states) {
+            ts.sgap = sgap;
+            ts.strans_records = ts.strans_entries * sgap;
+            if (!build_pass(d_states)) { // (the entries are complete; only the state table is lost)
+                (void)hipFree(d_states);
+                d_states = nullptr;
+                ts.strans_records = 0;
+                (void)hipGetLastError();
+            }
+        }
+    }
+    ts.trans_build_ms = ms_total;
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (d_desc) (void)hipFree(d_desc);
+    if (d_sink) (void)hipFree(d_sink);
     if (ok) {
         ts.d_trans = d_tab;
         ts.d_strans = d_states;
@@ -1001,18 +1028,18 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
             if (tl_building == 1) {
                 p.trans_dump = ts.d_trans;
                 p.strans_dump = ts.d_strans;
-                p.sgap = kStateGap;
+                p.sgap = ts.sgap;
             } else if (tl_building == 2) {
                 p.trans2_dump = ts.d_trans2;
                 p.gap_max = ts.gap_max;
                 if (!no_states && !(flags & BILD_NO_STATES)) {
                     p.strans = ts.d_strans;
-                    p.sgap = kStateGap;
+                    p.sgap = ts.sgap;
                 }
             } else if (p.prefix && !p.no_jump) {
                 if (ts.trans_state == 1 && !no_states && !(flags & BILD_NO_STATES)) {
                     p.strans = ts.d_strans;
-                    p.sgap = kStateGap;
+                    p.sgap = ts.sgap;
                 }
                 if (ts.trans_state == 0 && seen >= transients_after) ensure_transients(m, ts, st);
                 if (ts.trans_state == 1) {
@@ -1799,7 +1826,8 @@ int bild_trajset_create(const bild_model *m, int n_traj, const int32_t *T, const
             ts->descs[j].strans0 = rec * (m->S - 1); // S - 1 switches (one per OTHER state) for every prefix record
             rec += (int64_t)T[j] * m->S * ts->dstar_max;
         }
-        ts->strans_records = rec * (m->S - 1) * kStateGap;
+        ts->strans_entries = rec * (m->S - 1);
+        ts->strans_records = 0;
         ts->prefix_records = rec;
         ts->trans_entries = rec * m->S;
     }

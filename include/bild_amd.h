@@ -74,7 +74,11 @@ typedef enum bild_status {
 
 /* Do not start chains of close switches from the transient state table (see "prefix table" below: the state a transient
  * has reached when the next switch comes is a record of that table): every chain runs from its first switch.  Results are
- * bit-identical either way.  (Environment BILD_NO_STATES=1: never build the table.) */
+ * bit-identical either way.  (Environment BILD_NO_STATES=1: never build the table.  The table holds a record for every gap
+ * a chain can start with -- up to the set's longest converged transient, measured when the transient table is built -- and
+ * costs ~100 MB per 1000 frames of a 2-state trajectory: it is built for sets that need at most 4 GB of it, 64 GB for sets
+ * declared for >= 1e8 evaluations with bild_trajset_expect, BILD_STATES_MAX_BYTES=<n> otherwise; at most a third of the free
+ * memory in any case.) */
 #define BILD_NO_STATES 0x100u
 
 /* bild_model_create flags */
