@@ -104,6 +104,14 @@ _SIGNATURES = {
     'bild_amis_step_device_rng': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint, _dp]),
     'bild_amis_pool_samples': (ctypes.c_int, [_vp, _dp, _vp]),
     'bild_interval_marginals': (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int64, _ip, _ip, _dp, _dp]),
+    'bild_exchange_create': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.POINTER(_vp)]),
+    'bild_exchange_handle': (ctypes.c_int, [_vp, ctypes.c_char_p]),
+    'bild_exchange_connect': (ctypes.c_int, [_vp, ctypes.c_char_p]),
+    'bild_exchange_allgather': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, _vp, _vp]),
+    'bild_exchange_status': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int)]),
+    'bild_exchange_set_step': (ctypes.c_int, [_vp, ctypes.c_uint32]),
+    'bild_exchange_set_timeout': (ctypes.c_int, [_vp, ctypes.c_double]),
+    'bild_exchange_destroy': (ctypes.c_int, [_vp]),
     # the inference driver (run_host.cpp)
     'bild_run_create': (ctypes.c_int, [ctypes.c_int, _ip, ctypes.c_int, _vp, _vp, ctypes.c_int, _dp, _dp, _dp, _vp, _ip,
                                        ctypes.POINTER(_vp)]),
@@ -495,6 +503,51 @@ class CommHandle:
         if getattr(self, '_h', None) and _lib is not None:
             _lib.bild_comm_destroy(self._h)
             self._h = None
+
+
+EXCHANGE_HANDLE_BYTES = 64
+
+
+class ExchangeHandle:
+    """ owns a ``bild_exchange*``: the direct all-gather of a multi-GPU step (include/bild_amd.h, "the direct exchange") """
+
+    def __init__(self, world, rank, slot_doubles):
+        self.world, self.rank = int(world), int(rank)
+        self._h = _vp()
+        check(lib().bild_exchange_create(self.world, self.rank, int(slot_doubles), ctypes.byref(self._h)))
+
+    def handle(self):
+        buf = ctypes.create_string_buffer(EXCHANGE_HANDLE_BYTES)
+        check(lib().bild_exchange_handle(self._h, buf))
+        return buf.raw
+
+    def connect(self, handles):
+        """ handles: the 64-byte handles of all ranks, in rank order """
+        blob = b''.join(handles)
+        assert len(blob) == self.world * EXCHANGE_HANDLE_BYTES
+        check(lib().bild_exchange_connect(self._h, blob))
+
+    def allgather(self, d_send, d_recv, n_per_rank, stream=0):
+        check(lib().bild_exchange_allgather(self._h, int(d_send), int(n_per_rank), int(stream) if stream else None, int(d_recv)))
+
+    def status(self):
+        """ after the stream has been waited for: raises when a peer did not deliver within the timeout """
+        peer = ctypes.c_int(-1)
+        check(lib().bild_exchange_status(self._h, ctypes.byref(peer)))
+
+    def set_step(self, step):
+        check(lib().bild_exchange_set_step(self._h, int(step) & 0xffffffff))
+
+    def set_timeout(self, seconds):
+        check(lib().bild_exchange_set_timeout(self._h, float(seconds)))
+
+    def __del__(self):
+        h, self._h = getattr(self, '_h', None), None
+        if h:
+            try:
+                lib().bild_exchange_destroy(h)
+            except Exception:  # pragma: no cover  (interpreter shutdown)
+                pass
 
 
 class DeviceBuffer:

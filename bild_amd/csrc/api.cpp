@@ -237,7 +237,8 @@ struct bild_trajset {
     mutable double *d_strans = nullptr;   // transient state table (common.h), filled by the launch that builds the transient table
     mutable int64_t strans_records = 0;   // records of the state table as built: strans_entries * sgap
     mutable int64_t strans_entries = 0;   // (trajectory, chain, old state, new state, frame) combinations
-    mutable int sgap = kStateGap;         // records per entry: states 1 .. sgap - 1 frames behind the switch (sized when the table is built)
+    mutable int sgap = kStateGap;         // gaps 1 .. sgap - 1 behind a switch are covered (sized when the table is built) ...
+    mutable int sstride = kStateStride, snq = 0; // ... by snq records per entry, one for every sstride-th gap
     mutable int trans_m_max = 0;          // longest converged transient of the single table
     mutable int trans_m_typ = 48;         // typical frames-to-convergence of the table's entries (90th percentile): the scheduler's yardstick
 };
@@ -825,7 +826,9 @@ int ensure_transients(const bild_model &m, const bild_trajset &ts, hipStream_t s
     // a third of the free memory.  Which tables exist depends on the set and that declaration alone (reproducibility).
     if (ok && !config().no_states && !(ts.expected_evals >= 0 && ts.expected_evals < kExpectPairs) && ts.trans_m_max >= 2) {
         const int sgap = std::min<int>(kStateGap, ts.trans_m_max + 1);
-        const size_t sbytes = (size_t)ts.strans_entries * sgap * prefix_record_doubles(m.NPm[kModal]) * sizeof(double);
+        const int sstride = std::max(1, std::min(config().states_stride, 8));
+        const int snq = (sgap - 2) / sstride + 1; // records for g = 1, 1 + sstride, ... <= sgap - 1
+        const size_t sbytes = (size_t)ts.strans_entries * snq * prefix_record_doubles(m.NPm[kModal]) * sizeof(double);
         size_t budget = (size_t)std::max<int64_t>(config().states_max_bytes, 0);
         if (config().states_max_bytes < 0) budget = ts.expected_evals >= (int64_t)100000000 ? ((size_t)64 << 30) : ((size_t)4 << 30);
         if (sbytes <= budget && hipMemGetInfo(&free_b, &total_b) == hipSuccess && sbytes <= free_b / 3) {
@@ -836,7 +839,9 @@ int ensure_transients(const bild_model &m, const bild_trajset &ts, hipStream_t s
         }
         if (d_states) {
             ts.sgap = sgap;
-            ts.strans_records = ts.strans_entries * sgap;
+            ts.sstride = sstride;
+            ts.snq = snq;
+            ts.strans_records = ts.strans_entries * snq;
             if (!build_pass(d_states)) { // (the entries are complete; only the state table is lost)
                 (void)hipFree(d_states);
                 d_states = nullptr;
@@ -1029,17 +1034,23 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
                 p.trans_dump = ts.d_trans;
                 p.strans_dump = ts.d_strans;
                 p.sgap = ts.sgap;
+                p.sstride = ts.sstride;
+                p.snq = ts.snq;
             } else if (tl_building == 2) {
                 p.trans2_dump = ts.d_trans2;
                 p.gap_max = ts.gap_max;
                 if (!no_states && !(flags & BILD_NO_STATES)) {
                     p.strans = ts.d_strans;
                     p.sgap = ts.sgap;
+                    p.sstride = ts.sstride;
+                    p.snq = ts.snq;
                 }
             } else if (p.prefix && !p.no_jump) {
                 if (ts.trans_state == 1 && !no_states && !(flags & BILD_NO_STATES)) {
                     p.strans = ts.d_strans;
                     p.sgap = ts.sgap;
+                    p.sstride = ts.sstride;
+                    p.snq = ts.snq;
                 }
                 if (ts.trans_state == 0 && seen >= transients_after) ensure_transients(m, ts, st);
                 if (ts.trans_state == 1) {

@@ -38,3 +38,7 @@ int amis_dev_pass_a(const AmisView &, int64_t, int64_t, int64_t, double, double 
 int amis_dev_pass_b(const AmisView &, int64_t, double, int, const double *, double *, double *, int, void *) { return 1; }
 int amis_dev_pass_c(const AmisView &, int64_t, const double *, double, const double *, const double *, double *, int, void *) { return 1; }
 } // namespace bild
+#include "exchange.h"
+namespace bild {
+int launch_exchange(const ExParams &, void *) { return 1; }
+} // namespace bild

@@ -85,9 +85,14 @@ constexpr int prefix_record_doubles(int NP) { return (NP + kDMax) * NP + kDMax +
 // of the product of S, observed frames; the running log-likelihood is not used).  A chain of close switches -- a
 // transient that has not converged when the next switch comes -- then starts at its second switch from the record
 // (t, g = distance of the two switches) and continues the record's accumulators: the same numbers the candidate itself
-// would have produced, bit for bit, without running the g frames in between.  Records of
-// (trajectory, e, s, sn, t):  strans0 + ((((e * S + s) * (S - 1) + (sn - (sn > s))) * T + t) * kStateGap + g).
-constexpr int kStateGap = 64;
+// would have produced, bit for bit, without running the g frames in between.
+// The gaps are covered up to the set's longest converged transient (a chain of close switches begins with a gap shorter
+// than its first transient), and only every `sstride`-th gap has a record (g = 1, 1 + sstride, ...: a chain starts from the
+// last record at or in front of its second switch and runs the <= sstride - 1 frames in between itself -- a third of the
+// memory for 0.25 us more per chain at the default stride of 3).  Records of (trajectory, e, s, sn, t), snq per entry:
+//   (strans0 + (((e * S + s) * (S - 1) + (sn - (sn > s))) * T + t)) * snq + (g - 1) / sstride.
+constexpr int kStateGap = 64;   // largest gap ever covered
+constexpr int kStateStride = 3; // BILD_STATES_STRIDE
 
 struct KParams {
     const double *states; // S state blocks
@@ -124,7 +129,8 @@ struct KParams {
     // transient has reached there
     const double *strans;
     double *strans_dump;      // non-null: this launch (the one that builds the transient table) also fills the state table
-    int32_t sgap;             // records per switch: states 1 .. sgap - 1 frames behind it
+    int32_t sgap;             // gaps 1 .. sgap - 1 behind a switch are covered ...
+    int32_t sstride, snq;     // ... by a record for every sstride-th of them (g = 1 + q * sstride, q < snq records per switch)
     // work lists (walk.hip): this launch runs only the tasks the table walk could not finish -- kWorkBuckets lists of
     // `work_cap` task indices (index into `out`) each, heaviest bucket last, with their lengths in work_counts
     const int32_t *work;

@@ -824,13 +824,17 @@ __device__ __forceinline__ void logl_body(const KParams &p)
                 if (p.strans != nullptr && seg_in_lds && seg + 2 < nseg) {
                     const int sn = seg_state_of(seg + 1), t2 = seg_start_of(seg + 2), g1 = t2 - t;
                     if (sn != s && g1 >= 1 && g1 < p.sgap) {
+                        // the table keeps every `sstride`-th gap (g = 1, 1 + sstride, ...): the chain starts from the last
+                        // record at or in front of its second switch and runs the frames in between itself (at most
+                        // sstride - 1 of them, in the state of the gap) -- the frames the candidate would have run anyway
+                        const int q = (g1 - 1) / p.sstride, g0 = 1 + q * p.sstride;
                         const int64_t entry = (((int64_t)e * S + s) * (S - 1) + (sn - (sn > s ? 1 : 0))) * T + t;
-                        const double *__restrict__ rec = p.strans + ((td->strans0 + entry) * p.sgap + g1) * REC;
+                        const double *__restrict__ rec = p.strans + ((td->strans0 + entry) * p.snq + q) * REC;
                         ++seg; // the segment of sn: the frame at t2 moves on to the next one
                         s = sn;
                         next_start = t2;
-                        t = t2;
-                        start_from(rec, t2, true, t_ptr);
+                        t += g0;
+                        start_from(rec, t, true, t_ptr);
                         return;
                     }
                 }
@@ -981,7 +985,7 @@ __device__ __forceinline__ void logl_body(const KParams &p)
         const bool dump_states = JUMP && !kLean && building_transients && p.strans_dump != nullptr && K1 == 2 && nseg == 2;
         const int t_switch = dump_states ? seg_start_of(1) : 0;
         const int64_t state_rec0 = dump_states ? (td->strans0 + (((int64_t)e * S + seg_state_of(0)) * (S - 1) +
-                                                                 (seg_state_of(1) - (seg_state_of(1) > seg_state_of(0) ? 1 : 0))) * T + t_switch) * p.sgap
+                                                                 (seg_state_of(1) - (seg_state_of(1) > seg_state_of(0) ? 1 : 0))) * T + t_switch) * p.snq
                                                : 0;
         auto dump_state = [&](int g) {
             double *__restrict__ rec = p.strans_dump + (state_rec0 + g) * REC;
@@ -1124,7 +1128,8 @@ __device__ __forceinline__ void logl_body(const KParams &p)
                     for (int q = 0; q < CPL; ++q) asm volatile("" : "+v"(xn[q])); // (delivery of the next frame's data: see above)
                 }
                 if constexpr (JUMP) {
-                    if (dump_states && t < T && t - t_switch < p.sgap) dump_state(t - t_switch);
+                    if (dump_states && t < T && t - t_switch < p.sgap && (t - t_switch - 1) % p.sstride == 0)
+                        dump_state((t - t_switch - 1) / p.sstride);
                 }
                 if (JUMP && jumping && t == t_check && t < T) {
                     if (compare_with_table()) break;

@@ -146,6 +146,79 @@ class LibraryComm:
         self._comm.allgather(d_send, d_recv, n_per_rank, stream)
 
 
+class DirectExchange:
+    """
+    The step's collective as a one-shot peer write (include/bild_amd.h, "the direct exchange"; csrc/exchange_kernel.hip): ONE
+    kernel per rank stores the rank's shard into every peer's receive block and waits for theirs -- for the 10-256 KB a rank
+    contributes per AMIS step a ring all-gather is latency-bound, this is one hop.  Same interface as `LibraryComm`
+    (`ShardedModel(model, comm=DirectExchange.from_torch(slot))`); the 64-byte IPC handles of the receive blocks have to reach
+    every rank once, by any channel: an initialised ``torch.distributed`` group (`from_torch`) or files (`from_files`).  One
+    process per GPU; the device must be current before the exchange is created.  ``slot``: the longest shard, in doubles.
+    """
+
+    def __init__(self, world, rank, slot, handles=None):
+        from . import _lib
+        self.world, self.rank, self.slot = int(world), int(rank), int(slot)
+        self._x = _lib.ExchangeHandle(world, rank, slot)
+        if handles is not None:
+            self.connect(handles)
+
+    def handle(self):
+        return self._x.handle()
+
+    def connect(self, handles):
+        handles = list(handles)
+        handles[self.rank] = self._x.handle()
+        self._x.connect(handles)
+
+    @classmethod
+    def from_torch(cls, slot, group=None):
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        self = cls(world, rank, slot)
+        handles = [None] * world
+        dist.all_gather_object(handles, self.handle(), group=group)
+        self.connect(handles)
+        dist.barrier(group=group)       # (every rank has mapped every block before anybody stores into one)
+        return self
+
+    @classmethod
+    def from_files(cls, path, world, rank, slot, nonce, timeout=120.0):
+        """ rendezvous through a shared file system: rank r writes ``<path>.<nonce>.<r>``, reads the others', and all wait for all """
+        import os
+        import time
+        self = cls(world, rank, slot)
+        base = f"{path}.{nonce}"
+        tmp = f"{base}.{rank}.tmp"
+        with open(tmp, 'wb') as f:
+            f.write(self.handle())
+        os.replace(tmp, f"{base}.{rank}")
+        handles, t0 = [], time.time()
+        for r in range(world):
+            while not os.path.exists(f"{base}.{r}"):
+                if time.time() - t0 > timeout:
+                    raise TimeoutError(f"exchange handle of rank {r} did not appear")
+                time.sleep(0.005)
+            with open(f"{base}.{r}", 'rb') as f:
+                handles.append(f.read())
+        self.connect(handles)
+        # second phase: nobody stores into a block before everybody has mapped it
+        with open(f"{base}.{rank}.mapped", 'wb'):
+            pass
+        for r in range(world):
+            while not os.path.exists(f"{base}.{r}.mapped"):
+                if time.time() - t0 > timeout:
+                    raise TimeoutError(f"rank {r} did not map the exchange blocks")
+                time.sleep(0.005)
+        return self
+
+    def allgather(self, d_send, d_recv, n_per_rank, stream=0):
+        self._x.allgather(d_send, d_recv, n_per_rank, stream)
+
+    def status(self):
+        self._x.status()
+
+
 class ShardedModel:
     """
     Multi-GPU likelihood for an AMIS loop that runs replicated on every rank (same seed, hence the
@@ -221,6 +294,8 @@ class ShardedModel:
         comm.allgather(local.ptr, gathered.ptr, m, stream=0)          # default stream: ordered behind the kernel
         host = gathered.to_host(m * comm.world)                       # the one device -> host copy of the step
         self.host_copies += 1
+        if hasattr(comm, 'status'):
+            comm.status()                                             # (direct exchange: a peer that never delivered)
         self._verdict(host, hi > lo, ss, thetas, traj)
         return np.concatenate([host[r * m:r * m + sizes[r]] for r in range(comm.world)])
 

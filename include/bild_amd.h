@@ -30,7 +30,7 @@ extern "C" {
 #endif
 
 /* 2: round 4 -- bild_config_string / bild_config_reload, the inference driver (bild_run_*), the direct exchange
- *    (bild_comm_direct_*); negative cumulative positions of an (s, theta) row are refused on every path.
+ *    (bild_exchange_*); negative cumulative positions of an (s, theta) row are refused on every path.
  * 1: rounds 1-3 (the version constant was not bumped while entry points were added). */
 #define BILD_AMD_ABI_VERSION 2
 
@@ -363,6 +363,35 @@ int bild_comm_destroy(bild_comm *c);
 int bild_device_alloc(int64_t bytes, void **out);
 int bild_device_free(void *ptr);
 int bild_device_to_host(void *dst, const void *d_src, int64_t bytes, void *hip_stream);
+
+/* The direct exchange: the same all-gather as ONE kernel per rank that stores the rank's shard straight into every
+ * peer's receive block (mapped through an IPC handle; over xGMI between GPUs) and waits for the peers' shards there --
+ * for the 10-256 KB a rank contributes per AMIS step a ring collective is latency-bound (7 dependent hops on 8 GPUs), a
+ * one-shot peer write is one hop.  Replaces nothing in the reference (bild/amis.py:732-733 declines to
+ * parallelise); the vector it assembles is the one bild/amis.py:843-845 consumes.
+ *
+ *   every rank:  bild_exchange_create(world, rank, slot_doubles, &x)      on its current device; slot_doubles >= longest shard
+ *                bild_exchange_handle(x, handle)                          64 bytes, to be handed to every rank by any channel
+ *                bild_exchange_connect(x, handles)                        all ranks' handles in rank order (world x 64 bytes)
+ *   per step:    bild_logl_st_to_device(... stream, d_local)
+ *                bild_exchange_allgather(x, d_local, n, stream, d_all)    same stream; d_all: world x n doubles on the device
+ *                (consume d_all on that stream, or copy it to the host: bild_device_to_host)
+ *                bild_exchange_status(x, &peer)                           after the stream has been waited for: a peer that
+ *                                                                         did not deliver within the timeout (5 s) is an error
+ * Every rank must call bild_exchange_allgather the same number of times with the same n.  world <= 16.  The waits are
+ * bounded: a rank whose peer never arrives gets BILD_ERR_HIP from bild_exchange_status instead of a hung GPU.
+ * bild_exchange_set_step (tests: rehearse the wrap of the 32-bit step counter; the same call on every rank, with no
+ * exchange in flight) and bild_exchange_set_timeout are for tests and tools. */
+#define BILD_EXCHANGE_HANDLE_BYTES 64
+typedef struct bild_exchange bild_exchange;
+int bild_exchange_create(int world, int rank, int64_t slot_doubles, bild_exchange **out);
+int bild_exchange_handle(const bild_exchange *x, char *handle);
+int bild_exchange_connect(bild_exchange *x, const char *handles);
+int bild_exchange_allgather(bild_exchange *x, const double *d_send, int64_t n, void *hip_stream, double *d_recv);
+int bild_exchange_status(bild_exchange *x, int *peer);
+int bild_exchange_set_step(bild_exchange *x, uint32_t step);
+int bild_exchange_set_timeout(bild_exchange *x, double seconds);
+int bild_exchange_destroy(bild_exchange *x);
 
 /* canonical floating-point operations of one batch,
  *   F = (T-1)(4 N^3 d* + 2 N^2 d) + Tv((4 N^2 + 3 N) d* + 4 N d)      
