@@ -190,6 +190,9 @@ def main():
     ap.add_argument('--no-secondary', action='store_true', help='skip every side measurement (profiling runs that want the headline launches alone)')
     ap.add_argument('--no-seam', action='store_true', help='skip the api_seam measurement')
     ap.add_argument('--sweep', action='store_true', help='also the N x d* sweep of SURVEY 8(d) (chain lengths 4 ... 32, one and two localization errors)')
+    ap.add_argument('--exchange', default='rccl', choices=['rccl', 'direct'],
+                    help="the step's collective: 'rccl' = all_gather_into_tensor (ring), 'direct' = the library's one-shot peer "
+                         "write (bild_exchange_*: every rank stores its shard into every peer's receive block, one kernel)")
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help="collective backend; 'gloo' (log-likelihoods staged through host memory) rehearses the "
                          "multi-rank path on a box with fewer GPUs than ranks")
@@ -281,6 +284,7 @@ def main():
     d_all = torch.empty(pad * world, dtype=torch.float64, device=dev)
     turn = [0]
     coll_events = []
+    direct = bdist.DirectExchange.from_torch(pad) if (world > 1 and args.exchange == 'direct' and args.backend == 'nccl') else None
 
     def step(path=None, **kw):
         d_ss, d_th = d_batches[turn[0] % len(d_batches)]
@@ -291,7 +295,10 @@ def main():
             if args.backend == 'nccl':
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                bdist.all_gather_logl(d_out, d_all)
+                if direct is not None:
+                    direct.allgather(d_out.data_ptr(), d_all.data_ptr(), pad, stream_of())
+                else:
+                    bdist.all_gather_logl(d_out, d_all)
                 e1.record()
                 coll_events.append((e0, e1))
             else:
@@ -436,7 +443,7 @@ def main():
         'config': {'workload': workload, 'samples_this_rank': n, 'samples_global': n_global, 'T': T, 'k': k,
                    'states': args.states, 'path': args.path,
                    'entry': 'bild_logl_st_device: (s, theta) rows resident in HBM -> log-likelihoods in HBM',
-                   'collective': ('all_gather(float64[%d]) per step, %s' % (pad, args.backend)) if world > 1 else 'none (1 GPU)'},
+                   'collective': ('all_gather(float64[%d]) per step, %s' % (pad, 'direct exchange (bild_exchange_allgather)' if args.exchange == 'direct' and args.backend == 'nccl' else args.backend)) if world > 1 else 'none (1 GPU)'},
         'roofline': roofline,
     }
 
@@ -650,6 +657,17 @@ def main():
                 'tables_note': 'prefix + transient + pair tables; the transient STATE table (26 GB for this set, 0.8 s to allocate and '
                                'fill) is built for sets of up to 4 GB of it only, unless the caller declares >= 1e8 evaluations '
                                '(bild_trajset_expect) or sets BILD_STATES_MAX_BYTES'}
+            # the same set declared for a long life (bild_trajset_expect >= 1e8): the transient state table is built too
+            del ts_2
+            t0 = time.perf_counter()
+            ts_2 = model2.trajset(trajs2, expect=10 ** 9)
+            _lib.logl_st(model2.handle(), ts_2, ss2[:1000], th2[:1000], tid2[:1000])
+            build_s = time.perf_counter() - t0
+            per, kms_, wms_, fr_, _ = time_resident(model2.handle(), ts_2, d1, d2, d3, n_traj2 * per2, k + 1, 10)
+            b2, ms2 = _lib.prefix_info(ts_2)
+            result['config2_one_gpu']['declared_for_1e9_evaluations'] = {
+                'value': n_traj2 * per2 / per, 'unit': 'evals/s', 'ms_per_step': per * 1e3, 'frame_loop_kernel_ms': kms_,
+                'tables_bytes': b2, 'tables_build_ms_device': ms2, 'upload_and_first_evaluation_s': build_s}
             del d1, d2, d3, ts_2, model2
         except Exception as exc:   # (a side measurement must not take the headline down with it)
             result['config2_one_gpu'] = {'error': repr(exc)}
@@ -831,6 +849,9 @@ def main():
                 result['cpu_baseline_allcores'] = allc
                 result['speedup_vs_cpu_allcores'] = value / allc['value']
 
+    if direct is not None:
+        torch.cuda.synchronize()
+        direct.status()         # a peer that did not deliver within the timeout is an error, not a number
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

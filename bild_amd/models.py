@@ -190,7 +190,8 @@ class MultiStateRouse(MultiStateModel):
         expect : optional, the number of evaluations the set will see in total (`bild_trajset_expect`): a few single
             evaluations per trajectory are cheaper without the set's tables.  The declaration decides which tables the set
             builds (none below 300 evaluations, prefix + transient tables below 3000, all of them above or when nothing is
-            declared) and is therefore part of the cache key: a set declared for ten evaluations is never handed to an AMIS
+            declared -- the transient state table up to 4 GB, up to 64 GB from 1e8 evaluations on) and is therefore part of
+            the cache key: a set declared for ten evaluations is never handed to an AMIS
             run (which asks without a declaration), and the other way round.
 
         The cache is keyed by the IDENTITY of the trajectory objects, and an entry is trusted while the address and shape
@@ -207,7 +208,8 @@ class MultiStateRouse(MultiStateModel):
         prints, arrs = self._fingerprints(items)
         if expect is not None and expect < 0:
             raise ValueError("expect must be a non-negative number of evaluations")
-        table_class = 2 if expect is None or expect >= 3000 else (1 if expect >= 300 else 0)   # (api.cpp: kExpectPrefix, kExpectPairs)
+        # (api.cpp: kExpectPrefix, kExpectPairs, and the budget of the transient state table: 64 instead of 4 GB from 1e8 on)
+        table_class = 2 if expect is None else (3 if expect >= 10 ** 8 else 2 if expect >= 3000 else 1 if expect >= 300 else 0)
         key = (table_class,) + tuple(id(t) if p[0] is not None else p for t, p in zip(items, prints))
         hit = self._trajsets.get(key)
         if hit is not None:
