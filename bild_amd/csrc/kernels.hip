@@ -143,6 +143,47 @@ __device__ __forceinline__ void matvec_to_lds(XPtr X, const Cols<NP, CPL> &in, d
     // lane one row at a time keeps the operand registers of this (rare) path out of the budget of
     // the frame loop -- unless the geometry has registers to spare (ROOMY: two waves per SIMD, the frame loop over the
     // work lists, where a basis change is 2.6 us = nine frames of a chain): then two rows per trip, two trips in flight
+    if constexpr (ROOMY && CPL == 1) {
+        // Hand-scheduled (round 4).  Left to itself the compiler reads the five 16-byte pieces of a matrix row, WAITS for all
+        // of them, runs the row's ten FMAs, and only then asks for the next row: ten LDS latencies per product, 2.2 us per
+        // basis change -- ten frames' worth, paid two or three times by every chain that ends a launch.  Here the two rows of
+        // trip i + 1 are asked for BEFORE the FMAs of trip i (two register sets, 40 VGPRs: the frame loop's L / sgd / wq are
+        // dead across a basis change), and scheduling barriers keep the order: the product is then bound by its hundred FMAs.
+        // Every accumulator sees its terms in the order of the loop below (k ascending, even and odd k apart): bit-identical.
+        constexpr int H = NP / 2;
+        double2 cur[2][H], nxt[2][H];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int k2 = 0; k2 < H; ++k2) cur[r][k2] = *reinterpret_cast<const double2 *>(X + r * NP + 2 * k2);
+#pragma unroll
+        for (int i = 0; i < NP; i += 2) {
+            if (i + 2 < NP) {
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int k2 = 0; k2 < H; ++k2) nxt[r][k2] = *reinterpret_cast<const double2 *>(X + (i + 2 + r) * NP + 2 * k2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            double a[2] = {0.0, 0.0}, a2[2] = {0.0, 0.0};
+#pragma unroll
+            for (int k2 = 0; k2 < H; ++k2)
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    a[r] = fma(cur[r][k2].x, in.v[0][2 * k2], a[r]);
+                    a2[r] = fma(cur[r][k2].y, in.v[0][2 * k2 + 1], a2[r]);
+                }
+            a[0] += a2[0];
+            a[1] += a2[1];
+            if (store[0]) *reinterpret_cast<double2 *>(Tg + cidx[0] * NP + i) = make_double2(a[0], a[1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int k2 = 0; k2 < H; ++k2) cur[r][k2] = nxt[r][k2];
+        }
+        return;
+    }
     constexpr int R = (CPL == 1 && !ROOMY) ? 1 : 2;
     constexpr int kTrips = ROOMY ? NP / 2 : 1; // (ROOMY: the whole product unrolled, so that the LDS reads of the matrix run ahead of the FMAs)
 #pragma unroll kTrips
@@ -613,8 +654,18 @@ __device__ __forceinline__ void logl_body(const KParams &p)
                 const int c = isC[q] ? cidx[q] : (hasImg[q] ? cidx[q] * NP : 0);
                 const int st = isC[q] ? NP : 1;
                 const double keep = hasImg[q] ? 1.0 : 0.0;
+                if constexpr (JUMP && ((ROW && OCC <= 2) || kLean)) {
+                    // (all reads in flight, ONE wait: the compiler's own order is read, wait, multiply, ten times over)
+                    double tmp[NP];
 #pragma unroll
-                for (int i = 0; i < NP; ++i) col.v[q][i] = keep * scratch[c + i * st];
+                    for (int i = 0; i < NP; ++i) tmp[i] = scratch[c + i * st];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) col.v[q][i] = keep * tmp[i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) col.v[q][i] = keep * scratch[c + i * st];
+                }
             }
             wave_lds_fence();
             after_left();
