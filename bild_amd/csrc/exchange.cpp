@@ -29,6 +29,7 @@ struct bild_exchange {
     int world = 1, rank = 0, device = -1;
     int64_t slot = 0;
     uint32_t step = 1;
+    uint32_t arrivals[2] = {0, 0};    // arrivals every flag of a parity has seen so far (per peer), modulo 2^32
     char *block = nullptr;            // own receive block: data, then flags
     size_t data_bytes = 0, flag_bytes = 0;
     void *peer_base[bild::kExchangeMaxWorld] = {};  // mapped blocks of the peers (own block at [rank])
@@ -101,10 +102,14 @@ int bild_exchange_connect(bild_exchange *x, const char *handles)
 int bild_exchange_set_step(bild_exchange *x, uint32_t step)
 {
     if (!x) return fail(BILD_ERR_INVALID, "NULL handle");
-    std::vector<uint32_t> f((size_t)2 * x->world, step - 1u);
+    // (the flags count arrivals, kExchangeParts per step of their parity: start them, and the expectation, at a value that
+    // wraps where the step counter does)
+    const uint32_t base = step * (uint32_t)bild::kExchangeParts;
+    std::vector<uint32_t> f((size_t)2 * x->world, base);
     EX_HIP(hipDeviceSynchronize());
     EX_HIP(hipMemcpy(x->block + x->data_bytes, f.data(), f.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     x->step = step;
+    x->arrivals[0] = x->arrivals[1] = base;
     return BILD_OK;
 }
 
@@ -120,6 +125,8 @@ int bild_exchange_allgather(bild_exchange *x, const double *d_send, int64_t n, v
     p.n = n;
     p.slot = x->slot;
     p.step = x->step;
+    // flags count arrivals (kExchangeParts per step and parity, every second step): steps s, s - 2, ... of this parity
+    p.arrivals = x->arrivals[x->step & 1u] + (uint32_t)bild::kExchangeParts;
     for (int r = 0; r < x->world; ++r) {
         p.peer_data[r] = (double *)x->peer_base[r];
         p.peer_flags[r] = (uint32_t *)((char *)x->peer_base[r] + x->data_bytes);
@@ -130,6 +137,7 @@ int bild_exchange_allgather(bild_exchange *x, const double *d_send, int64_t n, v
     p.timeout_ticks = (unsigned long long)(x->timeout_s * 1e8);
     if (int rc = bild::launch_exchange(p, hip_stream))
         return fail(BILD_ERR_HIP, std::string("exchange kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
+    x->arrivals[x->step & 1u] += (uint32_t)bild::kExchangeParts;
     x->step += 1u;
     return BILD_OK;
 }

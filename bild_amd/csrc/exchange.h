@@ -5,11 +5,13 @@
 namespace bild {
 
 constexpr int kExchangeMaxWorld = 16;
+constexpr int kExchangeParts = 4; // workgroups per peer that share a shard (exchange_kernel.hip)
 
 struct ExParams {
     int world, rank;
     int64_t n, slot;
     uint32_t step;
+    uint32_t arrivals;                // what a flag of this step's parity reads once a peer's shard of this step is complete
     double *peer_data[kExchangeMaxWorld];    // data block of every rank (own block at [rank])
     uint32_t *peer_flags[kExchangeMaxWorld]; // flags block of every rank
     const double *send;

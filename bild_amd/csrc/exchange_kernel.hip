@@ -6,15 +6,16 @@
 //
 // Protocol.  Every rank owns a receive block in its own HBM, exported to the peers through an IPC handle:
 //     data   [2 parities][world slots][slot doubles]      slot r of parity q: rank r's shard of a step with step % 2 == q
-//     flags  [2 parities][world] uint32                   flags[q][r] = the step whose shard of rank r is complete in slot (q, r)
+//     flags  [2 parities][world] uint32                   flags[q][r] counts the arrivals of rank r's workgroups in slot (q, r)
 // A step (number `step`, counted per exchange object, the same on every rank) is one launch of `world` workgroups on the
 // caller's stream; workgroup p
-//     1. copies the local shard into slot (step % 2, rank) of PEER p's block (16-byte stores), then -- every storing wave
-//        drained, a system-scope release -- stores `step` into peer p's flags[step % 2][rank];
-//     2. polls its OWN flags[step % 2][p] until peer p's shard of this step has arrived (system-scope loads; the spin is
-//        bounded by a wall-clock timeout that sets a status word), acquires, and copies slot (step % 2, p) into the caller's
-//        gathered vector -- so the consumer of that vector reads bytes its own device wrote, whatever the caching of peer
-//        writes.
+//     1. copies its share of the local shard into slot (step % 2, rank) of PEER p's block with write-through stores, then --
+//        every storing wave drained, the workgroup's barrier -- one lane adds 1 to peer p's flags[step % 2][rank] (four
+//        workgroups per peer share a shard: four arrivals per step);
+//     2. polls its OWN flags[step % 2][p] until all of peer p's arrivals of this step are in (system-scope loads; the spin
+//        is bounded by a wall-clock timeout that sets a status word), acquires, and copies its share of slot (step % 2, p)
+//        into the caller's gathered vector -- so the consumer of that vector reads bytes its own device wrote, whatever the
+//        caching of peer writes.
 // Two parities: a rank can be at most one step ahead of a peer (it cannot finish step s + 1 before the peer has posted its
 // shard of s + 1, which the peer's stream does after it has consumed the results of step s), so the slots of step s are
 // never overwritten while somebody still reads them.  Step numbers are compared as signed differences: the 32-bit counter
@@ -28,49 +29,57 @@ namespace {
 
 constexpr int kThreads = 256;
 
+// kParts workgroups per peer share the shard (the stores of one workgroup to one peer are a few microseconds of one CU's
+// store queue; four CUs per peer hide that behind each other)
+constexpr int kParts = kExchangeParts;
+
 __global__ void __launch_bounds__(kThreads) exchange_kernel(const ExParams p)
 {
-    const int peer = blockIdx.x, tid = threadIdx.x;
+    const int peer = blockIdx.x / kParts, part = blockIdx.x % kParts, tid = threadIdx.x;
     const int par = (int)(p.step & 1u);
-    // 1. the local shard into the peer's block
+    const int64_t lo = p.n * part / kParts, hi = p.n * (part + 1) / kParts; // this workgroup's stretch of the shard
+    typedef __attribute__((address_space(1))) unsigned long long gu64;
+    // 1. the local shard into the peer's block: WRITE-THROUGH stores (system scope: they leave this device's caches as they
+    //    are issued), so no release fence -- which would write back every dirty line of the L2, microseconds -- is needed;
+    //    every storing wave drains its stores, the workgroup meets, ONE lane signals
     {
-        double *dst = p.peer_data[peer] + ((int64_t)par * p.world + p.rank) * p.slot;
-        const int64_t n2 = p.n / 2;
-        const double2 *s2 = reinterpret_cast<const double2 *>(p.send);
-        double2 *d2 = reinterpret_cast<double2 *>(dst);
-        for (int64_t i = tid; i < n2; i += kThreads) d2[i] = s2[i];
-        if ((p.n & 1) && tid == 0) dst[p.n - 1] = p.send[p.n - 1];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); // system scope: the stores of this wave are out before ...
-        __syncthreads();                               // ... any lane of the workgroup signals for them
+        gu64 *dst = (gu64 *)(p.peer_data[peer] + ((int64_t)par * p.world + p.rank) * p.slot);
+        const gu64 *src = (const gu64 *)p.send;
+        for (int64_t i = lo + tid; i < hi; i += kThreads) __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
         if (tid == 0)
-            __hip_atomic_store(p.peer_flags[peer] + par * p.world + p.rank, p.step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_fetch_add(p.peer_flags[peer] + par * p.world + p.rank, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    // 2. the peer's shard out of the own block
+    // 2. the peer's shard out of the own block: its kParts workgroups have each added 1 to the flag of (parity, peer) --
+    //    kParts per step, and the flag counts on from step to step
     {
         __shared__ int gave_up;
         if (tid == 0) {
             gave_up = 0;
             const uint32_t *flag = p.peer_flags[p.rank] + par * p.world + peer;
+            const uint32_t want = p.arrivals; // arrivals of this parity's flags after this step, modulo 2^32
             const unsigned long long t0 = wall_clock64();
             for (;;) {
                 const uint32_t seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if ((int32_t)(seen - p.step) >= 0) break;
+                if ((int32_t)(seen - want) >= 0) break;
                 if (wall_clock64() - t0 > p.timeout_ticks) {
                     gave_up = 1;
                     if (atomicCAS(p.status, 0u, 1u) == 0u) p.status[1] = (uint32_t)peer;
                     break;
                 }
-                __builtin_amdgcn_s_sleep(8);
+                __builtin_amdgcn_s_sleep(4);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); // (every wave reads the slot: each drops what its CU's caches may hold of it)
         if (gave_up) return;
+        // (the slot lies in THIS device's memory, whose coherence point is this device's L2: behind the acquire above -- one
+        // lane's, then the barrier -- plain loads read what the peer's write-through stores left there)
         const double *src = p.peer_data[p.rank] + ((int64_t)par * p.world + peer) * p.slot;
         double *dst = p.recv + (int64_t)peer * p.n;
-        // (p.n may be odd: the gathered vector's shards are then not 16-byte aligned -- 8-byte copies)
-        for (int64_t i = tid; i < p.n; i += kThreads) dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (int64_t i = lo + tid; i < hi; i += kThreads) dst[i] = src[i];
     }
 }
 
@@ -78,7 +87,7 @@ __global__ void __launch_bounds__(kThreads) exchange_kernel(const ExParams p)
 
 int launch_exchange(const ExParams &p, void *stream)
 {
-    hipLaunchKernelGGL(exchange_kernel, dim3((unsigned)p.world), dim3(kThreads), 0, reinterpret_cast<hipStream_t>(stream), p);
+    hipLaunchKernelGGL(exchange_kernel, dim3((unsigned)(p.world * kParts)), dim3(kThreads), 0, reinterpret_cast<hipStream_t>(stream), p);
     return (int)hipGetLastError();
 }
 
