@@ -50,7 +50,7 @@ ROTATE = 8                # distinct batches resident in HBM, one per step in tu
 
 
 def kernel_source_hash():
-    """ what the measured HBM traffic (profiles/r03_hbm_traffic.json) belongs to: the kernel sources it was measured on """
+    """ what the measured HBM traffic (profiles/r04_hbm_traffic.json) belongs to: the kernel sources it was measured on """
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, 'bild_amd', 'csrc')
     for name in sorted(os.listdir(csrc)):
@@ -400,14 +400,14 @@ def main():
     # ---- roofline of the dominant kernel: executed operations against the fp64 vector peak --------------------
     traffic, traffic_note = None, 'no measurement for this workload / these kernel sources'
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r03_hbm_traffic.json')) as f:
+        with open(os.path.join(ROOT, 'profiles', 'r04_hbm_traffic.json')) as f:
             tj = json.load(f)
         if tj['workload'] == {'samples': n, 'T': T, 'k': k, 'path': args.path} and args.states == 2:
             if tj.get('kernel_source_hash') == kernel_source_hash():
                 traffic = tj['traffic_bytes_corrected']
-                traffic_note = 'HBM bytes per step (both kernels), rocprofv3 PMC passes, gfx950 correction applied (profiles/r03_hbm_traffic.json)'
+                traffic_note = 'HBM bytes per step (both kernels), rocprofv3 PMC passes, gfx950 correction applied (profiles/r04_hbm_traffic.json)'
             else:
-                traffic_note = ('profiles/r03_hbm_traffic.json was measured on other kernel sources (hash %s, now %s): not quoted'
+                traffic_note = ('profiles/r04_hbm_traffic.json was measured on other kernel sources (hash %s, now %s): not quoted'
                                 % (tj.get('kernel_source_hash'), kernel_source_hash()))
     except Exception:
         pass

@@ -240,6 +240,7 @@ struct bild_trajset {
     mutable int sgap = kStateGap;         // gaps 1 .. sgap - 1 behind a switch are covered (sized when the table is built) ...
     mutable int sstride = kStateStride, snq = 0; // ... by snq records per entry, one for every sstride-th gap
     mutable int trans_m_max = 0;          // longest converged transient of the single table
+    mutable int two_switch_covered = 0;  // every candidate of <= 2 switches comes out of the tables (checked on the device when the pair table is built)
     mutable int trans_m_typ = 48;         // typical frames-to-convergence of the table's entries (90th percentile): the scheduler's yardstick
 };
 constexpr int kZeroPad = 8;
@@ -932,6 +933,22 @@ int ensure_pairs(const bild_model &m, const bild_trajset &ts, hipStream_t st)
     if (d_first) (void)hipFree(d_first);
     if (d_sink) (void)hipFree(d_sink);
     if (ok) {
+        // do the tables cover every candidate of at most two switches?  (schedule.hip: two_switch_cover_kernel)
+        std::vector<int64_t> ent((size_t)ts.n_traj + 1, 0);
+        for (int j = 0; j < ts.n_traj; ++j)
+            ent[(size_t)j + 1] = ent[j] + (int64_t)ts.descs[j].dstar * S * (S - 1) * std::max(ts.descs[j].T - 1, 0);
+        int64_t *d_ent = nullptr;
+        int *d_cov = nullptr;
+        int cov = 1;
+        const bool good = hipMalloc((void **)&d_ent, ent.size() * sizeof(int64_t)) == hipSuccess && hipMalloc((void **)&d_cov, sizeof(int)) == hipSuccess &&
+                          hipMemcpy(d_ent, ent.data(), ent.size() * sizeof(int64_t), hipMemcpyHostToDevice) == hipSuccess &&
+                          hipMemcpy(d_cov, &cov, sizeof(int), hipMemcpyHostToDevice) == hipSuccess &&
+                          launch_two_switch_cover(ts.d_descs, d_ent, ent.back(), ts.n_traj, S, ts.d_trans, d_tab, G, d_cov, (void *)st) == 0 &&
+                          hipStreamSynchronize(st) == hipSuccess && hipMemcpy(&cov, d_cov, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+        if (d_ent) (void)hipFree(d_ent);
+        if (d_cov) (void)hipFree(d_cov);
+        if (!good) (void)hipGetLastError();
+        ts.two_switch_covered = good && cov == 1 ? 1 : 0;
         ts.d_trans2 = d_tab;
         ts.trans2_entries = entries;
         ts.trans2_state = 1;
@@ -1139,6 +1156,9 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
             w.seg_state = d_seg_state;
         }
         w.convert_all = split ? 0 : 1;
+        // lists of <= 3 segments hold at most two switches: on a set whose tables cover every such candidate the walk finishes
+        // the whole batch, and the frame loop -- which would find its lists empty -- is not launched
+        w.no_lists = (split && K1 <= 3 && ts.two_switch_covered && p.trans2 != nullptr && !config().no_fused_launch) ? 1 : 0;
         if (split) {
             int32_t *d_work = nullptr, *d_lists = nullptr;
             const size_t list_bytes = (size_t)kWorkBuckets * (size_t)p.ntasks * sizeof(int32_t);
@@ -1223,7 +1243,9 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
         HIP_TRY(hipEventCreate(&e1));
         if (!ride) HIP_TRY(hipEventRecord(e0, st));
     }
-    int lrc = fam == kWide         ? launch_logl_wide(m.NP, p, grid, (void *)st)
+    const bool frame_loop_needed = !(split && K1 <= 3 && ts.two_switch_covered && p.trans2 != nullptr && !config().no_fused_launch);
+    int lrc = !frame_loop_needed   ? 0
+              : fam == kWide       ? launch_logl_wide(m.NP, p, grid, (void *)st)
               : fam == kModalTiles ? launch_logl_modal_mfma(m.NPm[kModal], p, (void *)st)
               : fam == kDenseTiles ? launch_logl_dense_mfma(m.NPm[kDense], p, (void *)st)
                                    : launch_logl(geom, mode, p, grid, lds, (void *)st, timing ? (void *)e0 : nullptr, timing ? (void *)e1 : nullptr);
@@ -1234,7 +1256,8 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
     if (work_alloc) (void)hipFreeAsync(work_alloc, st);
     if (lists_alloc) (void)hipFreeAsync(lists_alloc, st);
     if (timing) {
-        if (!ride) HIP_TRY(hipEventRecord(e1, st));
+        if (!frame_loop_needed) HIP_TRY(hipEventRecord(e0, st)); // (no dispatch for the events to ride on: an empty bracket)
+        if (!ride || !frame_loop_needed) HIP_TRY(hipEventRecord(e1, st));
         std::lock_guard<std::mutex> lk(g_time_mu);
         g_time_events.emplace_back(e0, e1);
         g_time_name = fam == kWide ? "logl_wide_kernel" : fam == kModalTiles ? "logl_modal_mfma_kernel" : fam == kDenseTiles ? "logl_dense_mfma_kernel" : kernel_name(geom, mode);

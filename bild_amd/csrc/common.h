@@ -159,6 +159,8 @@ struct WalkParams {
     int32_t *seg_out_start;
     int32_t *seg_out_state;
     int32_t convert_all; // no tables to walk: convert every list, finish nothing
+    int32_t no_lists;    // the host has proved that no task of this launch can need a frame (lists of <= 3 segments on a set whose
+                         // tables cover every candidate of two switches): no frame loop follows; a task that would be listed gets NaN
     int32_t *status;     // (s, theta) input: [0] != 0 when a row is not a point on the simplex / a state is out of range, [1] such a row
     const int32_t *traj_id; // may be null
     const double *Lc;       // running log-likelihood of the switch-free filters, one double per prefix record
@@ -234,6 +236,8 @@ size_t wide_lds_bytes(int NP);
 // schedule.hip: launch order computed on the device (workspace of device_schedule_bytes(n); everything on `stream`)
 int launch_pair_tasks(const int64_t *d_first_task, int n_traj, const TrajDesc *d_trajs, int S, int G, int64_t nb, int32_t *d_seg_start,
                       int32_t *d_seg_state, int32_t *d_traj_id, void *stream);
+int launch_two_switch_cover(const TrajDesc *d_trajs, const int64_t *d_first, int64_t total, int n_traj, int S, const TransEntry *trans,
+                            const TransEntry *trans2, int gap_max, int *d_covered, void *stream);
 size_t device_schedule_bytes(int64_t n);
 int device_schedule(const int32_t *d_seg_start, const int32_t *d_traj_id, const TrajDesc *d_trajs, int K1, int64_t n, int m_typ, int pairs,
                     int Tmax, int rpw, int64_t slots, void *ws, size_t ws_bytes, const int32_t **d_order, void *stream);

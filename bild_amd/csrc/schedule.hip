@@ -69,6 +69,46 @@ __global__ void __launch_bounds__(256) order_kernel(const int32_t *__restrict__ 
     order[i] = li < nw * rpw ? sorted[base + (li % rpw) * nw + li / rpw] : sorted[i];
 }
 
+// Do the tables cover EVERY candidate of at most two switches?  (api.cpp: a split launch of lists of <= 3 segments then hands
+// nothing to the frame loop, and its launch -- empty, but five microseconds of a twelve-microsecond step -- is not made.)
+// One thread per entry of the transient table (trajectory j, chain e, s -> sn, frame t): a single switch there must have an
+// entry (m > 0), and for every gap g in front of that transient's convergence a second switch sn -> sm at t + g must have its
+// pair entry.  Mirrors walk.hip's walk for K1 <= 3 term by term; any violation clears *covered.
+__global__ void __launch_bounds__(256) two_switch_cover_kernel(const TrajDesc *__restrict__ trajs, const int64_t *__restrict__ first,
+                                                               int n_traj, int S, const TransEntry *__restrict__ trans,
+                                                               const TransEntry *__restrict__ trans2, int gap_max, int *covered)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= first[n_traj]) return;
+    int j = 0;
+    while (first[j + 1] <= r) ++j;
+    const TrajDesc &td = trajs[j];
+    const int T = td.T;
+    int64_t q = r - first[j]; // ((e * S + s) * (S - 1) + sn') * (T - 1) + (t - 1)
+    const int t = 1 + (int)(q % (T - 1));
+    q /= (T - 1);
+    const int snp = (int)(q % (S - 1));
+    q /= (S - 1);
+    const int s = (int)(q % S), e = (int)(q / S);
+    const int sn = snp + (snp >= s ? 1 : 0);
+    bool ok = true;
+    const int m1 = trans[td.trans0 + (((int64_t)e * S + s) * S + sn) * T + t].m;
+    if (m1 <= 0 || t + m1 > T) ok = false;
+    const int g_end = ok ? ((m1 < T - t ? m1 : T - t)) : 0; // gaps 1 .. g_end - 1: the second switch comes before the first has converged
+    for (int g = 1; g < g_end && ok; ++g) {
+        if (g >= gap_max) {
+            ok = false;
+            break;
+        }
+        for (int sm = 0; sm < S; ++sm) {
+            if (sm == sn) continue;
+            const int m2 = trans2[(td.trans0 * S + ((((int64_t)e * S + s) * S + sn) * S + sm) * T + t) * gap_max + g].m;
+            if (m2 <= 0 || t + m2 > T) ok = false;
+        }
+    }
+    if (!ok) atomicAnd(covered, 0);
+}
+
 size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 // The candidates that build the pair table (api.cpp: ensure_pairs), written where they are needed: task r is
@@ -111,6 +151,16 @@ int launch_pair_tasks(const int64_t *d_first_task, int n_traj, const TrajDesc *d
     hipLaunchKernelGGL(pair_tasks_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_first_task, n_traj, d_trajs, S, G,
                        nb, d_seg_start, d_seg_state, d_traj_id);
     return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+// d_first: n_traj + 1 prefix sums of dstar_j * S * (S - 1) * (T_j - 1) (device); d_covered: one int, set to 1 by the caller
+int launch_two_switch_cover(const TrajDesc *d_trajs, const int64_t *d_first, int64_t total, int n_traj, int S, const TransEntry *trans,
+                            const TransEntry *trans2, int gap_max, int *d_covered, void *stream)
+{
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(two_switch_cover_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       d_trajs, d_first, n_traj, S, trans, trans2, gap_max, d_covered);
+    return (int)hipGetLastError();
 }
 
 size_t device_schedule_bytes(int64_t n)

@@ -284,6 +284,10 @@ __device__ __forceinline__ int walk_task(const WalkParams &p, const int64_t task
         }
         if (run_from >= 0 && !(links == 1 || (pairs && links == 2))) w += T - run_from;
     }
+    if (p.no_lists) { // (cannot happen: the host checked the tables entry by entry -- a visible NaN rather than a stale result if it did)
+        p.out[task] = __longlong_as_double(0x7ff8000000000000ll);
+        return -1;
+    }
     int bucket = w / kWorkBucketFrames;
     bucket = bucket < 0 ? 0 : (bucket >= kWorkBuckets ? kWorkBuckets - 1 : bucket);
     write_list();

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """
-Writes the counters of tools/profile_r03.sh (gpurun_out/r3/r03_pmc.txt: FETCH_SIZE / WRITE_SIZE per dispatch of the two kernels
-of a step) into profiles/r03_hbm_traffic.json and stamps it with the hash of the kernel sources they were measured at
+Writes the counters of tools/profile_r04.sh (gpurun_out/r4/r04_pmc.txt: FETCH_SIZE / WRITE_SIZE per dispatch of the two kernels
+of a step) into profiles/r04_hbm_traffic.json and stamps it with the hash of the kernel sources they were measured at
 (bench.py quotes `roofline.traffic` only while that hash matches).    python tools/restamp_traffic.py [pmc summary]
 """
 import json, os, re, sys
@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench
 
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, 'gpurun_out', 'r3', 'r03_pmc.txt')
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, 'gpurun_out', 'r4', 'r04_pmc.txt')
 vals, kernel = {}, None
 for line in open(src):
     if line.startswith('walk_kernel<'):
@@ -19,7 +19,7 @@ for line in open(src):
     m = re.match(r'\s+(FETCH_SIZE|WRITE_SIZE)\s+dispatches=\s*(\d+)\s+mean=\s*([\d.]+)', line)
     if m and kernel and int(m.group(2)) > 8:
         vals.setdefault(kernel, {})[m.group(1) + '_KiB'] = float(m.group(3))
-path = os.path.join(ROOT, 'profiles', 'r03_hbm_traffic.json')
+path = os.path.join(ROOT, 'profiles', 'r04_hbm_traffic.json')
 d = json.load(open(path))
 for k in ('walk_kernel', 'frame_loop_over_work_lists'):
     assert set(vals[k]) == {'FETCH_SIZE_KiB', 'WRITE_SIZE_KiB'}, vals
