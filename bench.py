@@ -796,7 +796,8 @@ def main():
                 per, kms_, wms_, fr_, _ = time_resident(hs, tss, d1, d2, None, n, k + 1, 20)
                 can_s, _ = _lib.flop_count(hs, tss, n)
                 rows[f'N={Nm} {name}'] = {'evals_per_s': n / per, 'ms_per_step': per * 1e3, 'frame_loop_kernel_ms': kms_, 'walk_kernel_ms': wms_,
-                                          'canonical_equiv_frac': can_s / per / 1e12 / FP64_PEAK_TFLOPS, 'modes': hs.query(_lib.Q_NEFF)}
+                                          'canonical_equiv_frac': can_s / per / 1e12 / FP64_PEAK_TFLOPS, 'modes': hs.query(_lib.Q_NEFF),
+                                          'frames_run_per_candidate': fr_ / n, 'tables_bytes': _lib.prefix_info(tss)[0]}
         result['sweep'] = {'what': f'{n} candidates x T={T}, k={k}: chain length N and distinct localization errors (SURVEY 8d)', **rows}
 
     if rank == 0 and world == 1 and args.scaling == 'weak':
