@@ -826,7 +826,7 @@ int ensure_transients(const bild_model &m, const bild_trajset &ts, hipStream_t s
     // caller has declared >= 1e8 evaluations on the set (then 64 GB) or BILD_STATES_MAX_BYTES says otherwise; always at most
     // a third of the free memory.  Which tables exist depends on the set and that declaration alone (reproducibility).
     if (ok && !config().no_states && !(ts.expected_evals >= 0 && ts.expected_evals < kExpectPairs) && ts.trans_m_max >= 2) {
-        const int sgap = std::min<int>(kStateGap, ts.trans_m_max + 1);
+        const int sgap = std::min<int>(std::max(2, std::min(config().states_max_gap, 255)), ts.trans_m_max + 1);
         const int sstride = std::max(1, std::min(config().states_stride, 8));
         const int snq = (sgap - 2) / sstride + 1; // records for g = 1, 1 + sstride, ... <= sgap - 1
         const size_t sbytes = (size_t)ts.strans_entries * snq * prefix_record_doubles(m.NPm[kModal]) * sizeof(double);

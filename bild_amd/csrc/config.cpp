@@ -42,6 +42,7 @@ void load(Config &c)
     flag("BILD_NO_STATES", c.no_states);
     num("BILD_STATES_MAX_BYTES", c.states_max_bytes);
     num("BILD_STATES_STRIDE", c.states_stride);
+    num("BILD_STATES_MAX_GAP", c.states_max_gap);
     num("BILD_PAIRS_MAX_GAP", c.pairs_max_gap);
     if (c.pairs_max_gap < 2) c.pairs_max_gap = 2;
     num("BILD_PAIRS_MAX_TASKS", c.pairs_max_tasks);
