@@ -24,6 +24,7 @@ NO_PREFIX = 0x20
 NO_JUMP = 0x40
 NO_SPLIT = 0x80
 NO_STATES = 0x100
+NO_TAIL = 0x200
 
 Q_N, Q_D, Q_S, Q_MODAL_OK, Q_NP, Q_NEFF, Q_HAS_G = range(7)
 X_LAMBDA, X_SIGMA, X_Q, X_WQ, X_R, X_C0Q, X_V = range(7)
@@ -299,18 +300,18 @@ class TrajSetHandle:
             self._h = None
 
 
-def logl_segments(model, ts, seg_start, seg_state, traj_id=None, path='auto', prefix=True, jump=True, split=True, states=True):
+def logl_segments(model, ts, seg_start, seg_state, traj_id=None, path='auto', prefix=True, jump=True, split=True, states=True, tail=True):
     seg_start, seg_state = i32(seg_start), i32(seg_state)
     n, K1 = seg_start.shape
     assert seg_state.shape == (n, K1)
     tid = None if traj_id is None else i32(traj_id)
     out = np.empty(n, dtype=np.float64)
     check(lib().bild_logl_segments(model._h, ts._h, n, K1, iptr(seg_start), iptr(seg_state), iptr(tid),
-                                   _flags(path, prefix=prefix, jump=jump, split=split, states=states), dptr(out)))
+                                   _flags(path, prefix=prefix, jump=jump, split=split, states=states, tail=tail), dptr(out)))
     return out
 
 
-def logl_st(model, ts, ss, thetas, traj_id=None, path='auto', prefix=True, jump=True, split=True):
+def logl_st(model, ts, ss, thetas, traj_id=None, path='auto', prefix=True, jump=True, split=True, tail=True):
     """ the sampler's (s, theta) batch as it is: switch frames are computed natively (bild_logl_st) """
     ss = f64(ss)
     thetas = np.ascontiguousarray(thetas, dtype=np.int64)
@@ -320,7 +321,7 @@ def logl_st(model, ts, ss, thetas, traj_id=None, path='auto', prefix=True, jump=
     assert ss.shape == (n, K1)
     tid = None if traj_id is None else i32(traj_id)
     out = np.empty(n, dtype=np.float64)
-    check(lib().bild_logl_st(model._h, ts._h, n, K1, dptr(ss), aptr(thetas), iptr(tid), _flags(path, prefix=prefix, jump=jump, split=split), dptr(out)))
+    check(lib().bild_logl_st(model._h, ts._h, n, K1, dptr(ss), aptr(thetas), iptr(tid), _flags(path, prefix=prefix, jump=jump, split=split, tail=tail), dptr(out)))
     return out
 
 
@@ -359,9 +360,9 @@ def logl_profiles(model, ts, states, traj_id=None, path='auto'):
     return out
 
 
-def _flags(path, validate=False, prefix=True, jump=True, split=True, states=True):
+def _flags(path, validate=False, prefix=True, jump=True, split=True, states=True, tail=True):
     return (PATHS[path] | (VALIDATE_DEVICE if validate else 0) | (0 if prefix else NO_PREFIX) | (0 if jump else NO_JUMP) |
-            (0 if split else NO_SPLIT) | (0 if states else NO_STATES))
+            (0 if split else NO_SPLIT) | (0 if states else NO_STATES) | (0 if tail else NO_TAIL))
 
 
 def frames_run_read(model):
@@ -416,13 +417,13 @@ def logl_segments_device(model, ts, n, K1, d_seg_start, d_seg_state, d_traj_id, 
                                           _vp(stream) if stream else None, _vp(d_out)))
 
 
-def logl_st_device(model, ts, n, K1, d_ss, d_thetas, d_out, d_traj_id=0, stream=0, path='auto', d_status=0, split=True, states=True):
+def logl_st_device(model, ts, n, K1, d_ss, d_thetas, d_out, d_traj_id=0, stream=0, path='auto', d_status=0, split=True, states=True, tail=True):
     """
     the sampler's (s, theta) rows resident in HBM (raw device pointers: float64 n x K1, uint8 n x K1), results to d_out;
     asynchronous on `stream` (bild_logl_st_device)
     """
     check(lib().bild_logl_st_device(model._h, ts._h, n, K1, _vp(d_ss), _vp(d_thetas), _vp(d_traj_id) if d_traj_id else None,
-                                    _flags(path, split=split, states=states), _vp(stream) if stream else None, _vp(d_out),
+                                    _flags(path, split=split, states=states, tail=tail), _vp(stream) if stream else None, _vp(d_out),
                                     _vp(d_status) if d_status else None))
 
 

@@ -217,6 +217,7 @@ struct bild_trajset {
     mutable std::mutex prefix_mu;
     mutable std::atomic<int> prefix_state{0};
     mutable double *d_prefix = nullptr;
+    mutable double *d_tail_g = nullptr;   // first-order tails (tail.hip): kDMax x NP doubles per prefix record
     mutable double *d_prefix_L = nullptr; // running log-likelihood of every record, densely (walk.hip reads nothing else)
     mutable int64_t prefix_records = 0;
     mutable double prefix_build_ms = 0.0;
@@ -703,6 +704,31 @@ int ensure_prefix(const bild_model &m, const bild_trajset &ts, hipStream_t st)
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
     cleanup(ok);
+    if (ok && !m.has_G && !config().no_tail) {
+        // the first-order tails beside the table (tail.hip): one backward pass per (trajectory, chain, state)
+        double *d_g = nullptr;
+        KParams q{};
+        fill_params(m, ts, kModal, q);
+        hipEvent_t t0 = nullptr, t1 = nullptr;
+        const size_t gbytes = (size_t)ts.prefix_records * kDMax * NP * sizeof(double);
+        bool good = hipMalloc((void **)&d_g, gbytes) == hipSuccess && hipEventCreate(&t0) == hipSuccess && hipEventCreate(&t1) == hipSuccess;
+        if (good) {
+            (void)hipEventRecord(t0, st);
+            good = launch_tail(ts.d_descs, ts.n_traj, S, NP, m.d, ts.dstar_max, q.states, d_tab, d_g, (void *)st) == 0;
+            (void)hipEventRecord(t1, st);
+            good = good && hipStreamSynchronize(st) == hipSuccess;
+            float ms = 0.f;
+            if (good && hipEventElapsedTime(&ms, t0, t1) == hipSuccess) ts.prefix_build_ms += ms;
+        }
+        if (t0) (void)hipEventDestroy(t0);
+        if (t1) (void)hipEventDestroy(t1);
+        if (good) {
+            ts.d_tail_g = d_g;
+        } else {
+            if (d_g) (void)hipFree(d_g);
+            (void)hipGetLastError();
+        }
+    }
     if (ok) {
         ts.d_prefix = d_tab;
         ts.d_prefix_L = d_L;
@@ -1046,6 +1072,7 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
             const int64_t transients_after = after_env ? config().tables_after : kTransientsAfter;
             if (ts.prefix_state == 0 && seen >= prefix_after) ensure_prefix(m, ts, st);
             if (ts.prefix_state == 1) p.prefix = ts.d_prefix;
+            if (ts.prefix_state == 1 && !tl_building && !(flags & BILD_NO_TAIL)) p.tail_g = ts.d_tail_g;
             const bool no_states = config().no_states;
             if (tl_building == 1) {
                 p.trans_dump = ts.d_trans;
@@ -1891,6 +1918,7 @@ int bild_trajset_destroy(bild_trajset *ts)
     if (ts->d_descs) (void)hipFree(ts->d_descs);
     if (ts->d_prefix) (void)hipFree(ts->d_prefix);
     if (ts->d_prefix_L) (void)hipFree(ts->d_prefix_L);
+    if (ts->d_tail_g) (void)hipFree(ts->d_tail_g);
     if (ts->d_trans) (void)hipFree(ts->d_trans);
     if (ts->d_trans2) (void)hipFree(ts->d_trans2);
     if (ts->d_strans) (void)hipFree(ts->d_strans);

@@ -131,6 +131,9 @@ struct KParams {
     double *strans_dump;      // non-null: this launch (the one that builds the transient table) also fills the state table
     int32_t sgap;             // gaps 1 .. sgap - 1 behind a switch are covered ...
     int32_t sstride, snq;     // ... by a record for every sstride-th of them (g = 1 + q * sstride, q < snq records per switch)
+    // first-order tail (tail.hip): per prefix record kDMax x NP doubles g -- what a deviation of the means from the record does to
+    // the log-likelihood of all later frames; null: a transient is run until its means have converged too
+    const double *tail_g;
     // work lists (walk.hip): this launch runs only the tasks the table walk could not finish -- kWorkBuckets lists of
     // `work_cap` task indices (index into `out`) each, heaviest bucket last, with their lengths in work_counts
     const int32_t *work;
@@ -177,6 +180,8 @@ struct WalkParams {
     int32_t debug;                  // timing experiments only (BILD_WALK_DEBUG; wrong results): 1 no pair loads, 2 no append, 4 no loads at all
 };
 int launch_walk(const WalkParams &p, void *stream, void *ev_start = nullptr, void *ev_stop = nullptr);
+int launch_tail(const TrajDesc *d_trajs, int n_traj, int S, int NP, int d, int dstar_max, const double *d_states, const double *d_prefix,
+                double *d_tail_g, void *stream);
 int launch_mark_refused_rows(const int32_t *seg_start, int K1, int64_t n, double *out, void *stream);
 
 // launch geometry for a padded chain length

@@ -40,6 +40,7 @@ void load(Config &c)
     flag("BILD_NO_TRANSIENTS", c.no_transients);
     flag("BILD_NO_PAIRS", c.no_pairs);
     flag("BILD_NO_STATES", c.no_states);
+    flag("BILD_NO_TAIL", c.no_tail);
     num("BILD_STATES_MAX_BYTES", c.states_max_bytes);
     num("BILD_STATES_STRIDE", c.states_stride);
     num("BILD_STATES_MAX_GAP", c.states_max_gap);

@@ -14,6 +14,7 @@ struct Config {
     bool no_transients = false;  // BILD_NO_TRANSIENTS    no transient table
     bool no_pairs = false;       // BILD_NO_PAIRS         no pair table
     bool no_states = false;      // BILD_NO_STATES        no transient state table
+    bool no_tail = false;        // BILD_NO_TAIL          no first-order tails: a transient runs until its means have converged too
     int64_t states_max_bytes = -1;                // BILD_STATES_MAX_BYTES  (-1: 4 GB, 64 GB for sets declared for >= 1e8 evaluations)
     int states_max_gap = 64;                      // BILD_STATES_MAX_GAP    largest gap the state table covers (<= 255)
     int states_stride = 3;                        // BILD_STATES_STRIDE     the state table keeps every n-th gap (1 ... 8)

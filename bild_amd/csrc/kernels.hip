@@ -690,6 +690,7 @@ __device__ __forceinline__ void logl_body(const KParams &p)
         constexpr int kJumpFirst = BILD_JUMP_FIRST; // first comparison this many frames behind a switch
         int t_check = 0; // frame index (frames < t_check are processed) at which the next convergence check is due
         int s_loaded = s; // state whose vectors (wq, L, sgd) are in registers
+        int t_seg = 0, s_from = s; // the switch the current segment began with: its frame, and the state in front of it (first-order tail)
         // frame t is the first of a new segment: state bookkeeping, and the basis change of a real switch
         auto enter_segment = [&](int t) {
             {
@@ -710,6 +711,8 @@ __device__ __forceinline__ void logl_body(const KParams &p)
 #endif
                         }
                     }
+                    s_from = s;
+                    t_seg = t;
                     s = sn;
                     load_state(s);
                     s_loaded = s;
@@ -825,6 +828,16 @@ __device__ __forceinline__ void logl_body(const KParams &p)
             tot += (double)nd * (logS + (double)nv * kLog2Pi);
             return -0.5 * tot;
         };
+        // sum of one value per lane over the lanes of the task, in lane order (the same in every lane of the task)
+        auto group_sum = [&](double v) {
+            scratch[gl] = v;
+            wave_lds_fence();
+            double tot = 0.0;
+#pragma unroll
+            for (int g2 = 0; g2 < G; ++g2) tot += scratch[g2];
+            wave_lds_fence();
+            return tot;
+        };
         auto reset_piece = [&]() {
 #pragma unroll
             for (int q = 0; q < CPL; ++q) accq[q] = 0.0;
@@ -882,6 +895,8 @@ __device__ __forceinline__ void logl_body(const KParams &p)
                         const int64_t entry = (((int64_t)e * S + s) * (S - 1) + (sn - (sn > s ? 1 : 0))) * T + t;
                         const double *__restrict__ rec = p.strans + ((td->strans0 + entry) * p.snq + q) * REC;
                         ++seg; // the segment of sn: the frame at t2 moves on to the next one
+                        s_from = s;
+                        t_seg = t;
                         s = sn;
                         next_start = t2;
                         t += g0;
@@ -1067,6 +1082,13 @@ __device__ __forceinline__ void logl_body(const KParams &p)
             // per lane: largest deviation of the own column(s) from the table's, in units of the tolerance
             double excess = 0.0;
             bool same = true;
+            // first-order tail (tail.hip): the covariance columns must have converged as before; a mean column may still be
+            // kTailTol = 2^-24 away -- what that deviation does to every later frame is a dot product with the table's g
+            constexpr double kTailTol = 5.9604644775390625e-08;
+            constexpr int kTailMargin = 8; // frames beyond the table's own transient before the next switch may come
+            const bool tails = JUMP && p.tail_g != nullptr && !building_transients;
+            bool near = true;
+            double excess_t = 0.0;
 #pragma unroll
             for (int q = 0; q < CPL; ++q) {
                 if (!hasImg[q]) continue;
@@ -1084,9 +1106,46 @@ __device__ __forceinline__ void logl_body(const KParams &p)
                 const double bar = kJumpTol * ref;
                 same = same && (dev <= bar); // a NaN anywhere never compares equal
                 excess = fmax(excess, dev > bar ? dev / fmax(bar, 1e-300) : 0.0);
+                const double bar_t = isM[q] ? kTailTol * ref : bar;
+                near = near && (dev <= bar_t);
+                excess_t = fmax(excess_t, dev > bar_t ? dev / fmax(bar_t, 1e-300) : 0.0);
             }
             const unsigned long long agree = __ballot(same);
-            if ((agree & group_mask) != group_mask) {
+            bool converged = (agree & group_mask) == group_mask;
+            double tail_term = 0.0;
+            if (tails && !converged) {
+                const double excess_full = excess;
+                excess = excess_t; // (the next look is scheduled by what still has to happen before the tail can be taken)
+                if ((__ballot(near) & group_mask) == group_mask) {
+                    // may the rest of the segment come out of the table?  Only if the means will have converged by the next
+                    // switch: the table knows how long a transient from a synchronised start takes at this very place (the
+                    // entry of the switch this segment began with), a chain's last transient gets kTailMargin frames more
+                    const int t2 = next_start < T ? next_start : T;
+                    bool far = t2 >= T;
+                    if (!far && p.trans != nullptr && t_seg >= 1) {
+                        const int m_ref = p.trans[td->trans0 + (((int64_t)e * S + s_from) * S + s) * T + t_seg].m;
+                        far = m_ref > 0 && t2 - t_seg >= m_ref + kTailMargin;
+                    }
+                    if (far) {
+                        converged = true;
+                        double mine = 0.0;
+#pragma unroll
+                        for (int q = 0; q < CPL; ++q)
+                            if (isM[q]) {
+                                const double *__restrict__ gq =
+                                    p.tail_g + ((td->prefix_rec0 + ((int64_t)e * S + s) * T + (t - 1)) * kDMax + (cidx[q] - NP)) * NP;
+                                double acc = 0.0;
+#pragma unroll
+                                for (int i = 0; i < NP; ++i) acc = fma(gq[i], col.v[q][i] - rec[cidx[q] * NP + i], acc);
+                                mine += acc;
+                            }
+                        tail_term = group_sum(mine);
+                    } else {
+                        excess = excess_full; // no tail in front of so close a switch: full convergence, as without tails
+                    }
+                }
+            }
+            if (!converged) {
                 // not yet: the deviation shrinks geometrically (the default Rouse model: 0.73 bits per frame), so the
                 // next look comes after about the frames the worst column still needs at 1.3 frames per bit -- by the
                 // lower edge of its bucket, i.e. rather too early than too late; a slower filter is simply asked again
@@ -1099,8 +1158,9 @@ __device__ __forceinline__ void logl_body(const KParams &p)
                 if (__ballot(!(excess < 0x1p60)) & group_mask) wait = 64; // far off, or not a number
                 t_check = t + wait;
             } else {
-                // converged at frame t: the own piece ends here
+                // converged at frame t: the own piece ends here (with what the remaining deviation of the means still adds)
                 extra += piece_value();
+                extra += tail_term;
                 open_run = 0;
                 nrun += t;
                 if (building_transients) return true;
