@@ -1088,7 +1088,6 @@ __device__ __forceinline__ void logl_body(const KParams &p)
             constexpr int kTailMargin = 8; // frames beyond the table's own transient before the next switch may come
             const bool tails = JUMP && p.tail_g != nullptr && !building_transients;
             bool near = true;
-            double excess_t = 0.0;
 #pragma unroll
             for (int q = 0; q < CPL; ++q) {
                 if (!hasImg[q]) continue;
@@ -1108,14 +1107,15 @@ __device__ __forceinline__ void logl_body(const KParams &p)
                 excess = fmax(excess, dev > bar ? dev / fmax(bar, 1e-300) : 0.0);
                 const double bar_t = isM[q] ? kTailTol * ref : bar;
                 near = near && (dev <= bar_t);
-                excess_t = fmax(excess_t, dev > bar_t ? dev / fmax(bar_t, 1e-300) : 0.0);
             }
             const unsigned long long agree = __ballot(same);
             bool converged = (agree & group_mask) == group_mask;
             double tail_term = 0.0;
             if (tails && !converged) {
-                const double excess_full = excess;
-                excess = excess_t; // (the next look is scheduled by what still has to happen before the tail can be taken)
+                // (The comparisons stay where the table BUILDERS made theirs -- the next look is scheduled by the full criterion,
+                // tails or not: a transient must never be found converged at a frame its builder did not look at, or a chain
+                // that starts from the state table -- which skips the frames in front of its second switch, comparisons
+                // included -- and the same chain run from its first switch would part ways by a tolerance.)
                 if ((__ballot(near) & group_mask) == group_mask) {
                     // may the rest of the segment come out of the table?  Only if the means will have converged by the next
                     // switch: the table knows how long a transient from a synchronised start takes at this very place (the
@@ -1140,8 +1140,6 @@ __device__ __forceinline__ void logl_body(const KParams &p)
                                 mine += acc;
                             }
                         tail_term = group_sum(mine);
-                    } else {
-                        excess = excess_full; // no tail in front of so close a switch: full convergence, as without tails
                     }
                 }
             }

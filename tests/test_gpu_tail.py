@@ -47,8 +47,12 @@ def test_tails_against_frame_by_frame(built_lib, N, S, T, k, miss, err):
     assert f_tail <= f_plain                                      # never more frames
     if miss == 'none' and k <= 8:
         assert f_tail < 0.9 * f_plain                             # ... and markedly fewer where chains end in a long segment
-    # the tails change nothing about the invariances: single launch == split launch, bit for bit
+    # the tails change nothing about the invariances: single launch == split launch == chains run from their first switch
+    # instead of the state table, bit for bit
     assert np.array_equal(with_tail, _lib.logl_st(h, ts, ss, th, split=False))
+    a, b = _lib.segments_from_st(ss, th, T, S)
+    assert np.array_equal(with_tail, _lib.logl_segments(h, ts, a, b, states=False))
+    assert np.array_equal(with_tail, _lib.logl_segments(h, ts, a, b, states=False, split=False))
     pick = rng.choice(len(ss), 40, replace=False)
     want = oracle.logl_batch(model.arrays(), model.measurement, model.localization_error, traj[:], H.expand(ss[pick], th[pick], T))
     assert np.max(np.abs(with_tail[pick] - want)) < 1e-8
