@@ -180,6 +180,10 @@ struct bild_model {
         hipStream_t stream = nullptr;
         bool taken = false;
         int work_set = 0;
+        // held from the flip of `work_set` until BOTH kernels of the launch are enqueued: two threads launching on one
+        // (model, stream) must enqueue in the order in which they flipped, or a walk would count into a set the frame loop of
+        // the launch in front of it still reads
+        std::mutex launch_mu;
     };
     mutable WorkSlot slots[2];
     // the block of stream `st`, or null (caller holds `mu`)
@@ -1137,6 +1141,7 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
                        p.walk_lds && ts.d_prefix_L != nullptr && p.ntasks <= (int64_t)INT_MAX;
     int32_t *work_alloc = nullptr, *lists_alloc = nullptr;
     bild_model::WorkSlot *used_slot = nullptr; // the persistent work-list block this launch alternates the counter set of
+    std::unique_lock<std::mutex> slot_order;   // (WorkSlot::launch_mu: released when this function returns, by whatever path)
     auto release = [&]() {
         if (ts.dstar_max > 1) (void)hipFreeAsync(target, st);
         if (work_alloc) (void)hipFreeAsync(work_alloc, st);
@@ -1190,8 +1195,13 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
             int32_t *d_work = nullptr, *d_lists = nullptr;
             const size_t list_bytes = (size_t)kWorkBuckets * (size_t)p.ntasks * sizeof(int32_t);
             {
+                bild_model::WorkSlot *slot;
+                {
+                    std::lock_guard<std::mutex> lk(m.mu);
+                    slot = m.slot_for(st);
+                }
+                if (slot) slot_order = std::unique_lock<std::mutex>(slot->launch_mu); // (never taken under m.mu: no lock order to get wrong)
                 std::lock_guard<std::mutex> lk(m.mu);
-                bild_model::WorkSlot *slot = m.slot_for(st);
                 if (slot) {
                     DeviceBuf &ws_work = slot->ws_work;
                     if (ws_work.cap < kWorkHeader + list_bytes) {
@@ -1235,9 +1245,15 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
             p.order = nullptr; // the work lists ARE the launch order
         }
         hipEvent_t w0 = nullptr, w1 = nullptr;
-        if (timing) {
-            HIP_TRY(hipEventCreate(&w0));
-            HIP_TRY(hipEventCreate(&w1));
+        if (timing && (hipEventCreate(&w0) != hipSuccess || hipEventCreate(&w1) != hipSuccess)) {
+            // (behind the flip: the walk will not run, so the other counter set is not zeroed -- the next launch must not take it)
+            if (used_slot) {
+                std::lock_guard<std::mutex> lk(m.mu);
+                used_slot->work_set = 1 - used_slot->work_set;
+            }
+            if (w0) (void)hipEventDestroy(w0);
+            release();
+            return fail(BILD_ERR_HIP, "timing events: hipEventCreate failed");
         }
         const int wrc = launch_walk(w, (void *)st, (void *)w0, (void *)w1); // (timed: the events ride on the dispatch)
         if (wrc != 0) {
