@@ -353,6 +353,15 @@ __device__ __forceinline__ void logl_body(const KParams &p)
         unsigned long long clock_events = 0;                   // (== 2: ticks inside comparisons / jumps, and how many)
         int n_events = 0;
 #endif
+        // (the listed frame loop: a lone task's prologue is a string of dependent memory round trips -- the task's list is asked
+        // for HERE, beside the trajectory descriptor, not behind it; lane i holds entry i, lists of up to kSegLds segments)
+        int32_t pre_start = 0, pre_state = 0;
+        if constexpr (kLean) {
+            if (K1 <= kSegLds && gl < K1) {
+                pre_start = p.seg_start[r * K1 + gl];
+                pre_state = p.seg_state[r * K1 + gl];
+            }
+        }
         const int tj = p.traj_id ? p.traj_id[r] : 0;
         const TrajDesc *__restrict__ td = p.trajs + tj;
         if (e >= td->dstar) {
@@ -421,9 +430,16 @@ __device__ __forceinline__ void logl_body(const KParams &p)
         int nseg = K1;
         if (seg_in_lds) {
             volatile int32_t *const sl = seg_lds;
-            for (int i = gl; i < K1; i += (BLK || ROW) ? 16 : G) {
-                sl[i] = sst[i];
-                sl[kSegLds + i] = ssv[i];
+            if constexpr (kLean && (BLK || ROW)) { // (16 lanes per task: one entry per lane, loaded at the top of the task)
+                if (gl < K1) {
+                    sl[gl] = pre_start;
+                    sl[kSegLds + gl] = pre_state;
+                }
+            } else {
+                for (int i = gl; i < K1; i += (BLK || ROW) ? 16 : G) {
+                    sl[i] = sst[i];
+                    sl[kSegLds + i] = ssv[i];
+                }
             }
             wave_lds_fence();
             int cnt = 1, prev = sl[kSegLds];
@@ -923,7 +939,22 @@ __device__ __forceinline__ void logl_body(const KParams &p)
                 const double la = record_of(s1, ti - 1)[kRecL], lb = record_of(s1, t3 - 1)[kRecL];
                 double v2 = 0.0;
                 int m2 = 0;
-                if (p.trans2 != nullptr && n2 < T && n2 - ti < p.gap_max) {
+                if constexpr (kLean) {
+                    // every load of the plan in ONE round trip: the pair entry and its running sums are asked for
+                    // unconditionally, with indices of entry 0 where there is no pair (walk.hip does the same)
+                    const bool pair_ok = p.trans2 != nullptr && n2 < T && n2 - ti < p.gap_max;
+                    const int sm = pair_ok ? seg_lds[kSegLds + i + 1] : 0;
+                    const int n4 = (pair_ok && i + 2 < nseg) ? seg_lds[i + 2] : INT_MAX;
+                    const int t4 = n4 < T ? n4 : T;
+                    const TransEntry *tab2 = p.trans2 != nullptr ? p.trans2 : p.trans;
+                    const int64_t i2 = pair_ok ? (td->trans0 * S + ((((int64_t)e * S + s0) * S + s1) * S + sm) * T + ti) * p.gap_max + (n2 - ti) : td->trans0;
+                    const TransEntry e2 = tab2[i2];
+                    const double l4 = record_of(sm, t4 - 1)[kRecL], l2 = record_of(sm, ti - 1)[kRecL];
+                    if (pair_ok) {
+                        v2 = e2.c + (l4 - l2);
+                        m2 = e2.m;
+                    }
+                } else if (p.trans2 != nullptr && n2 < T && n2 - ti < p.gap_max) {
                     const int sm = seg_lds[kSegLds + i + 1];
                     const int n4 = (i + 2 < nseg) ? seg_lds[i + 2] : INT_MAX;
                     const int t4 = n4 < T ? n4 : T;
