@@ -91,7 +91,7 @@ constexpr int prefix_record_doubles(int NP) { return (NP + kDMax) * NP + kDMax +
 // last record at or in front of its second switch and runs the <= sstride - 1 frames in between itself -- a third of the
 // memory for 0.25 us more per chain at the default stride of 3).  Records of (trajectory, e, s, sn, t), snq per entry:
 //   (strans0 + (((e * S + s) * (S - 1) + (sn - (sn > s))) * T + t)) * snq + (g - 1) / sstride.
-constexpr int kStateGap = 64;   // largest gap ever covered
+constexpr int kStateGap = 255;  // largest gap that can ever be covered (BILD_STATES_MAX_GAP: 128 by default)
 constexpr int kStateStride = 3; // BILD_STATES_STRIDE
 
 struct KParams {

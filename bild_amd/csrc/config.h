@@ -16,7 +16,7 @@ struct Config {
     bool no_states = false;      // BILD_NO_STATES        no transient state table
     bool no_tail = false;        // BILD_NO_TAIL          no first-order tails: a transient runs until its means have converged too
     int64_t states_max_bytes = -1;                // BILD_STATES_MAX_BYTES  (-1: 4 GB, 64 GB for sets declared for >= 1e8 evaluations)
-    int states_max_gap = 64;                      // BILD_STATES_MAX_GAP    largest gap the state table covers (<= 255)
+    int states_max_gap = 128;                     // BILD_STATES_MAX_GAP    largest gap the state table covers (<= 255; 64 until round 4)
     int states_stride = 3;                        // BILD_STATES_STRIDE     the state table keeps every n-th gap (1 ... 8)
     int pairs_max_gap = 128;                      // BILD_PAIRS_MAX_GAP
     int64_t pairs_max_tasks = (int64_t)40 << 20;  // BILD_PAIRS_MAX_TASKS
