@@ -1077,6 +1077,8 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
             if (ts.prefix_state == 0 && seen >= prefix_after) ensure_prefix(m, ts, st);
             if (ts.prefix_state == 1) p.prefix = ts.d_prefix;
             if (ts.prefix_state == 1 && !tl_building && !(flags & BILD_NO_TAIL)) p.tail_g = ts.d_tail_g;
+            p.tail_tol = std::ldexp(1.0, -std::max(8, std::min(config().tail_tol_bits, 43)));
+            p.tail_margin = std::max(0, config().tail_margin);
             const bool no_states = config().no_states;
             if (tl_building == 1) {
                 p.trans_dump = ts.d_trans;

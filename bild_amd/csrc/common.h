@@ -134,6 +134,8 @@ struct KParams {
     // first-order tail (tail.hip): per prefix record kDMax x NP doubles g -- what a deviation of the means from the record does to
     // the log-likelihood of all later frames; null: a transient is run until its means have converged too
     const double *tail_g;
+    double tail_tol;     // a mean column may be this far (relative) from the table's when the tail is taken
+    int32_t tail_margin; // frames beyond the table's own transient before the next switch may come
     // work lists (walk.hip): this launch runs only the tasks the table walk could not finish -- kWorkBuckets lists of
     // `work_cap` task indices (index into `out`) each, heaviest bucket last, with their lengths in work_counts
     const int32_t *work;

@@ -1115,8 +1115,8 @@ __device__ __forceinline__ void logl_body(const KParams &p)
             bool same = true;
             // first-order tail (tail.hip): the covariance columns must have converged as before; a mean column may still be
             // kTailTol = 2^-24 away -- what that deviation does to every later frame is a dot product with the table's g
-            constexpr double kTailTol = 5.9604644775390625e-08;
-            constexpr int kTailMargin = 8; // frames beyond the table's own transient before the next switch may come
+            const double kTailTol = p.tail_tol;  // (2^-24 unless BILD_TAIL_TOL_BITS says otherwise)
+            const int kTailMargin = p.tail_margin; // frames beyond the table's own transient before the next switch may come (8)
             const bool tails = JUMP && p.tail_g != nullptr && !building_transients;
             bool near = true;
 #pragma unroll
@@ -1155,7 +1155,20 @@ __device__ __forceinline__ void logl_body(const KParams &p)
                     bool far = t2 >= T;
                     if (!far && p.trans != nullptr && t_seg >= 1) {
                         const int m_ref = p.trans[td->trans0 + (((int64_t)e * S + s_from) * S + s) * T + t_seg].m;
-                        far = m_ref > 0 && t2 - t_seg >= m_ref + kTailMargin;
+                        // ... and by what the means still have to lose: `excess` is their deviation in units of the full
+                        // tolerance; a transient from a synchronised start lost ~30 bits (a deviation of 2^-13 of the scale
+                        // down to 2^-43) in m_ref frames, so `bits` more take bits * m_ref / 30 frames -- a chain's last
+                        // transient starts further off than a single switch's and is asked for more (soak: 3-state chains)
+                        int bits = 40;
+                        if (!(__ballot(excess >= 0x1p36) & group_mask)) bits = 36;
+                        if (!(__ballot(excess >= 0x1p32) & group_mask)) bits = 32;
+                        if (!(__ballot(excess >= 0x1p28) & group_mask)) bits = 28;
+                        if (!(__ballot(excess >= 0x1p24) & group_mask)) bits = 24;
+                        if (!(__ballot(excess >= 0x1p20) & group_mask)) bits = 20;
+                        if (!(__ballot(excess >= 0x1p16) & group_mask)) bits = 16;
+                        if (!(__ballot(excess >= 0x1p12) & group_mask)) bits = 12;
+                        if (!(__ballot(excess >= 0x1p8) & group_mask)) bits = 8;
+                        far = m_ref > 0 && t2 - t_seg >= m_ref + kTailMargin && t2 - t >= (bits * m_ref + 29) / 30 + 4;
                     }
                     if (far) {
                         converged = true;

@@ -25,6 +25,7 @@ def _frames(model, fn):
 
 @pytest.mark.parametrize('N,S,T,k,miss,err', [(20, 2, 1000, 4, 'none', 0.1), (20, 2, 1000, 8, 'none', 0.1), (20, 2, 600, 6, 'iid', 0.1),
                                               (20, 3, 800, 5, 'bursty', [0.1, 0.1, 0.3]), (32, 2, 1000, 4, 'none', 0.1),
+                                              (24, 3, 700, 10, 'none', 0.1), (20, 3, 676, 7, 'none', 0.3),
                                               (12, 2, 400, 12, 'none', 0.05)])
 def test_tails_against_frame_by_frame(built_lib, N, S, T, k, miss, err):
     import bild_amd
@@ -44,6 +45,9 @@ def test_tails_against_frame_by_frame(built_lib, N, S, T, k, miss, err):
           f"{np.max(np.abs(with_tail - exact)):.1e}, |no tail - frame by frame| {np.max(np.abs(without - exact)):.1e}")
     assert np.max(np.abs(with_tail - exact)) < 2e-10 * scale
     assert np.max(np.abs(without - exact)) < 2e-10 * scale
+    # the tails add nothing to the deviation the tables already have (a fixed margin behind the table's own transient let a
+    # chain's last transient of a 3-state model through with 6e-10; the frames asked for now follow the measured deviation)
+    assert np.max(np.abs(with_tail - exact)) < np.max(np.abs(without - exact)) + 2e-11 * scale
     assert f_tail <= f_plain                                      # never more frames
     if miss == 'none' and k <= 8:
         assert f_tail < 0.9 * f_plain                             # ... and markedly fewer where chains end in a long segment
