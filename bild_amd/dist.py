@@ -178,8 +178,18 @@ class DirectExchange:
         self = cls(world, rank, slot)
         handles = [None] * world
         dist.all_gather_object(handles, self.handle(), group=group)
-        self.connect(handles)
-        dist.barrier(group=group)       # (every rank has mapped every block before anybody stores into one)
+        # every rank maps every block; the verdicts are exchanged in a collective ALL ranks reach whatever happened to them (a
+        # rank that raised on its own here would leave the others waiting in theirs), and it is also the point behind which
+        # every block is mapped everywhere: nobody stores into one before
+        problem = None
+        try:
+            self.connect(handles)
+        except Exception as err:
+            problem = f"rank {rank}: {err!r}"
+        problems = [None] * world
+        dist.all_gather_object(problems, problem, group=group)
+        if any(p is not None for p in problems):
+            raise RuntimeError("direct exchange: mapping the receive blocks failed: " + "; ".join(p for p in problems if p))
         return self
 
     @classmethod
