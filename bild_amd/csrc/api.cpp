@@ -710,15 +710,23 @@ int ensure_prefix(const bild_model &m, const bild_trajset &ts, hipStream_t st)
     cleanup(ok);
     if (ok && !m.has_G && !config().no_tail) {
         // the first-order tails beside the table (tail.hip): one backward pass per (trajectory, chain, state)
-        double *d_g = nullptr;
+        double *d_g = nullptr, *d_gain = nullptr;
+        int64_t *d_first = nullptr;
         KParams q{};
         fill_params(m, ts, kModal, q);
         hipEvent_t t0 = nullptr, t1 = nullptr;
         const size_t gbytes = (size_t)ts.prefix_records * kDMax * NP * sizeof(double);
-        bool good = hipMalloc((void **)&d_g, gbytes) == hipSuccess && hipEventCreate(&t0) == hipSuccess && hipEventCreate(&t1) == hipSuccess;
+        std::vector<int64_t> first((size_t)ts.n_traj + 1, 0); // blocks of the parallel phase, trajectory by trajectory
+        for (int j = 0; j < ts.n_traj; ++j) first[(size_t)j + 1] = first[j] + (int64_t)ts.dstar_max * S * ts.descs[j].T;
+        bool good = first.back() == ts.prefix_records && first.back() < ((int64_t)1 << 31) &&
+                    hipMalloc((void **)&d_g, gbytes) == hipSuccess &&
+                    hipMalloc((void **)&d_gain, (size_t)ts.prefix_records * (NP + 4) * sizeof(double)) == hipSuccess &&
+                    hipMalloc((void **)&d_first, first.size() * sizeof(int64_t)) == hipSuccess &&
+                    hipMemcpy(d_first, first.data(), first.size() * sizeof(int64_t), hipMemcpyHostToDevice) == hipSuccess &&
+                    hipEventCreate(&t0) == hipSuccess && hipEventCreate(&t1) == hipSuccess;
         if (good) {
             (void)hipEventRecord(t0, st);
-            good = launch_tail(ts.d_descs, ts.n_traj, S, NP, m.d, ts.dstar_max, q.states, d_tab, d_g, (void *)st) == 0;
+            good = launch_tail(ts.d_descs, ts.n_traj, S, NP, m.d, ts.dstar_max, q.states, d_tab, d_first, first.back(), d_gain, d_g, (void *)st) == 0;
             (void)hipEventRecord(t1, st);
             good = good && hipStreamSynchronize(st) == hipSuccess;
             float ms = 0.f;
@@ -726,6 +734,8 @@ int ensure_prefix(const bild_model &m, const bild_trajset &ts, hipStream_t st)
         }
         if (t0) (void)hipEventDestroy(t0);
         if (t1) (void)hipEventDestroy(t1);
+        if (d_gain) (void)hipFree(d_gain);
+        if (d_first) (void)hipFree(d_first);
         if (good) {
             ts.d_tail_g = d_g;
         } else {
@@ -856,13 +866,25 @@ int ensure_transients(const bild_model &m, const bild_trajset &ts, hipStream_t s
     // caller has declared >= 1e8 evaluations on the set (then 64 GB) or BILD_STATES_MAX_BYTES says otherwise; always at most
     // a third of the free memory.  Which tables exist depends on the set and that declaration alone (reproducibility).
     if (ok && !config().no_states && !(ts.expected_evals >= 0 && ts.expected_evals < kExpectPairs) && ts.trans_m_max >= 2) {
-        const int sgap = std::min<int>(std::max(2, std::min(config().states_max_gap, 255)), ts.trans_m_max + 1);
+        int sgap = std::min<int>(std::max(2, std::min(config().states_max_gap, 255)), ts.trans_m_max + 1);
         const int sstride = std::max(1, std::min(config().states_stride, 8));
-        const int snq = (sgap - 2) / sstride + 1; // records for g = 1, 1 + sstride, ... <= sgap - 1
-        const size_t sbytes = (size_t)ts.strans_entries * snq * prefix_record_doubles(m.NPm[kModal]) * sizeof(double);
+        int snq = (sgap - 2) / sstride + 1; // records for g = 1, 1 + sstride, ... <= sgap - 1
+        const size_t per_q = (size_t)ts.strans_entries * prefix_record_doubles(m.NPm[kModal]) * sizeof(double);
         size_t budget = (size_t)std::max<int64_t>(config().states_max_bytes, 0);
         if (config().states_max_bytes < 0) budget = ts.expected_evals >= (int64_t)100000000 ? ((size_t)64 << 30) : ((size_t)4 << 30);
-        if (sbytes <= budget && hipMemGetInfo(&free_b, &total_b) == hipSuccess && sbytes <= free_b / 3) {
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min(budget, free_b / 3);
+        else budget = 0;
+        // a table that would not fit covers the SHORT gaps (every chain saves its basis change, the frames saved grow with the
+        // gap): as many records per switch as the budget holds, none below gaps of ~16 -- for sets of up to 32 trajectories:
+        // what the table saves is the latency of a launch's longest chain, which does not grow with the number of
+        // trajectories, while its cost does (configs[2], 256 trajectories: -11 % per step for 8.7 GB and 0.3 s)
+        if ((size_t)snq * per_q > budget && per_q > 0) {
+            snq = ts.n_traj <= 32 ? (int)(budget / per_q) : 0;
+            sgap = snq * sstride + 1;
+            if (snq * sstride < 16) snq = 0;
+        }
+        const size_t sbytes = (size_t)snq * per_q;
+        if (snq > 0) {
             if (hipMalloc((void **)&d_states, sbytes) != hipSuccess) {
                 d_states = nullptr;
                 (void)hipGetLastError();

@@ -31,7 +31,7 @@ size_t device_schedule_bytes(int64_t) { return 0; }
 int device_schedule(const int32_t *, const int32_t *, const TrajDesc *, int, int64_t, int, int, int, int, int64_t, void *, size_t, const int32_t **, void *) { return 1; }
 int launch_logl_wide(int, const KParams &, int, void *) { return 1; }
 int launch_walk(const WalkParams &, void *, void *, void *) { return 1; }
-int launch_tail(const TrajDesc *, int, int, int, int, int, const double *, const double *, double *, void *) { return 1; }
+int launch_tail(const TrajDesc *, int, int, int, int, int, const double *, const double *, const int64_t *, int64_t, double *, double *, void *) { return 1; }
 int launch_mark_refused_rows(const int32_t *, int, int64_t, double *, void *) { return 1; }
 int amis_dev_pass_a_rows(int64_t, int64_t) { return 0; }
 int amis_dev_draw(int, int, int64_t, uint64_t, uint64_t, const double *, const double *, const uint8_t *, double *, uint8_t *, void *) { return 1; }

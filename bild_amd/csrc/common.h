@@ -183,7 +183,7 @@ struct WalkParams {
 };
 int launch_walk(const WalkParams &p, void *stream, void *ev_start = nullptr, void *ev_stop = nullptr);
 int launch_tail(const TrajDesc *d_trajs, int n_traj, int S, int NP, int d, int dstar_max, const double *d_states, const double *d_prefix,
-                double *d_tail_g, void *stream);
+                const int64_t *d_first, int64_t total, double *d_gain, double *d_tail_g, void *stream);
 int launch_mark_refused_rows(const int32_t *seg_start, int K1, int64_t n, double *out, void *stream);
 
 // launch geometry for a padded chain length

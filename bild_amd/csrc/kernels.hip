@@ -706,7 +706,13 @@ __device__ __forceinline__ void logl_body(const KParams &p)
         constexpr int kJumpFirst = BILD_JUMP_FIRST; // first comparison this many frames behind a switch
         int t_check = 0; // frame index (frames < t_check are processed) at which the next convergence check is due
         int s_loaded = s; // state whose vectors (wq, L, sgd) are in registers
-        int t_seg = 0, s_from = s; // the switch the current segment began with: its frame, and the state in front of it (first-order tail)
+        // the switch the current segment began with -- its frame, and the state in front of it (first-order tail) -- lives in the
+        // task's second LDS constant: two registers live across the frame loop cost the geometries that are short of them
+        // another round of spills (the pair table's builder, (2, 7): 420 -> 700 us when they were registers)
+        auto note_switch = [&](int s_from, int t_seg) {
+            row_const[1] = __hiloint2double(s_from, t_seg);
+        };
+        note_switch(s, 0);
         // frame t is the first of a new segment: state bookkeeping, and the basis change of a real switch
         auto enter_segment = [&](int t) {
             {
@@ -727,8 +733,7 @@ __device__ __forceinline__ void logl_body(const KParams &p)
 #endif
                         }
                     }
-                    s_from = s;
-                    t_seg = t;
+                    note_switch(s, t);
                     s = sn;
                     load_state(s);
                     s_loaded = s;
@@ -911,8 +916,7 @@ __device__ __forceinline__ void logl_body(const KParams &p)
                         const int64_t entry = (((int64_t)e * S + s) * (S - 1) + (sn - (sn > s ? 1 : 0))) * T + t;
                         const double *__restrict__ rec = p.strans + ((td->strans0 + entry) * p.snq + q) * REC;
                         ++seg; // the segment of sn: the frame at t2 moves on to the next one
-                        s_from = s;
-                        t_seg = t;
+                        note_switch(s, t);
                         s = sn;
                         next_start = t2;
                         t += g0;
@@ -1153,6 +1157,9 @@ __device__ __forceinline__ void logl_body(const KParams &p)
                     // entry of the switch this segment began with), a chain's last transient gets kTailMargin frames more
                     const int t2 = next_start < T ? next_start : T;
                     bool far = t2 >= T;
+                    wave_lds_fence();
+                    const double noted = row_const[1];
+                    const int t_seg = __double2loint(noted), s_from = __double2hiint(noted);
                     if (!far && p.trans != nullptr && t_seg >= 1) {
                         const int m_ref = p.trans[td->trans0 + (((int64_t)e * S + s_from) * S + s) * T + t_seg].m;
                         // ... and by what the means still have to lose: `excess` is their deviation in units of the full

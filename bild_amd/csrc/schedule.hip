@@ -81,7 +81,11 @@ __global__ void __launch_bounds__(256) two_switch_cover_kernel(const TrajDesc *_
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= first[n_traj]) return;
     int j = 0;
-    while (first[j + 1] <= r) ++j;
+    for (int hi = n_traj; hi - j > 1;) { // first[j] <= r < first[j + 1]
+        const int mid = (j + hi) / 2;
+        if (first[mid] <= r) j = mid;
+        else hi = mid;
+    }
     const TrajDesc &td = trajs[j];
     const int T = td.T;
     int64_t q = r - first[j]; // ((e * S + s) * (S - 1) + sn') * (T - 1) + (t - 1)
