@@ -1057,13 +1057,11 @@ int launch_batch(const bild_model &m, const bild_trajset &ts, int64_t n, int K1,
             // (... including the room for the walk plan in the workgroup's share of the LDS)
             if (listed_geometry(geom, &lg) &&
                 lds_bytes(m, lg, mode) + (size_t)lg.W * (64 / lg.G) * kWalkDoubles * sizeof(double) <= (size_t)160 * 1024 / (size_t)std::max(1, (4 * lg.OCC + lg.W - 1) / lg.W)) {
-                // A geometry at ONE wave per SIMD pays only while the list fits the chip once (it is latency-bound then); the
-                // list is written on the device, so its length is estimated: switches spread evenly over the trajectory, a
-                // candidate is listed when two neighbouring gaps are both shorter than a transient (10k x k = 4: 4 %, k = 8:
-                // a third).  A matter of speed only (configs[3]: k = 4 269 -> 297 M evals/s with it, k = 8 127 -> 97 M).
-                const double kk = K1 - 1, gap = 1.0 - std::exp(-(double)ts.trans_m_typ * (kk + 1) / (double)std::max(ts.Tmax, 1));
-                const double listed = (double)n * ts.dstar_max * std::min(1.0, 0.5 * std::max(kk - 1, 0.0) * gap * gap);
-                if (lg.OCC >= 2 || listed <= 1024.0 * lg.tasks_per_wave()) geom = lg;
+                // (Rounds 2-3 took a geometry at ONE wave per SIMD only while the estimated list fitted the chip once.  Since the lean
+                // frame loop -- no spills at 16 / 20 modes, against 270 / 600 spilled registers of the batch geometries -- it wins at
+                // every list length measured: chains of 32 / 40 beads, 10 000 ... 100 000 candidates, k = 4 / 8: 1.3-2.0x / 2.5x;
+                // BASELINE configs[3] at k = 8: 335 -> 196 us.  tools/listed_rule.py, BILD_NO_LISTED_GEOMETRY for the comparison.)
+                geom = lg;
             }
         }
         lds = lds_bytes(m, geom, mode);

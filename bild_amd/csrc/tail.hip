@@ -13,7 +13,7 @@
 // The recursion is run once per (trajectory, chain, state), right behind the prefix table, and leaves g for every record
 // (kDMax x NP doubles, beside the table: KParams::tail_g) -- in two kernels: what it needs of the table's filter at every frame
 // (gain, innovations) is recomputed for all frames in parallel, the pass that is sequential in t then moves one double per
-// lane and frame (3.1 -> ~0.5 ms per T = 1000 trajectory against one kernel that did both).  The frame loop then leaves a transient as
+// lane and frame (3.1 ms per T = 1000 trajectory in one kernel that did both -> 0.8 ms in two -> see tail_scan_kernel).  The frame loop then leaves a transient as
 // soon as its covariance has converged and its means are within 2^-24 of the table's (delta^2 terms < 1e-13), adds
 // g . delta, and takes the table's sums for the rest of the segment -- if the next switch is far enough away for the means
 // to have converged by then (kernels.hip: compare_with_table).  NumPy experiment behind it (default model, N = 20 / 32): jump
@@ -89,50 +89,91 @@ __global__ void __launch_bounds__(64) tail_gain_kernel(const TrajDesc *__restric
     if (lane == kDMax) out[NP + kDMax] = 1.0;
 }
 
-// Phase 2, sequential over frames: one wavefront per task runs  g_{t-1} = (e_t / S_t) Lambda w + Lambda (g_t - w (K_t . g_t))  backwards
-// (Lambda g_t over a missing frame); what it needs per frame is one double per lane and three scalars, asked for a frame ahead
+// Phase 2, sequential over frames:  g_{t-1} = (e_t / S_t) Lambda w + Lambda (g_t - w (K_t . g_t))  backwards (Lambda g_t over a missing frame).
+// The three dimensions of a task sit side by side in one wavefront -- rows of W = 16 lanes (W = 32 above 16 modes: two wavefronts
+// per task), lane i of a row owns mode i of its dimension --, so that K_t . g_t is ONE butterfly over a row for all of them, in
+// DPP moves (no LDS round trips: four ds_bpermute steps per dimension were 0.79 us of every frame, 0.8 ms of a T = 1000
+// trajectory's first evaluation); what a frame needs from memory -- one double per lane and two scalars -- is asked for
+// kTailChunk frames ahead.
+constexpr int kTailChunk = 16;
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// sum over the 16 lanes of a DPP row, the same in every lane of the row
+__device__ __forceinline__ double row_sum16(double v)
+{
+    v += dpp_move<0xB1>(v);  // quad_perm [1, 0, 3, 2]
+    v += dpp_move<0x4E>(v);  // quad_perm [2, 3, 0, 1]
+    v += dpp_move<0x141>(v); // row_half_mirror
+    v += dpp_move<0x140>(v); // row_mirror
+    return v;
+}
+
+template <int W>
 __global__ void __launch_bounds__(64) tail_scan_kernel(const TrajDesc *__restrict__ trajs, int n_traj, int S, int NP, int dstar_max,
                                                        const double *__restrict__ states, const double *__restrict__ gain,
                                                        double *__restrict__ tail_g)
 {
-    const int task = blockIdx.x; // (j * dstar_max + e) * S + s
+    constexpr int kDimsPerWave = 64 / W, kParts = (kDMax + kDimsPerWave - 1) / kDimsPerWave;
+    const int task = blockIdx.x / kParts, part = blockIdx.x % kParts; // task = (j * dstar_max + e) * S + s
     const int s = task % S, e = (task / S) % dstar_max, j = task / (S * dstar_max);
     if (j >= n_traj) return;
     const TrajDesc &td = trajs[j];
     if (e >= td.dstar) return;
     const int lane = threadIdx.x, T = td.T;
-    const bool row = lane < NP;
-    const int i = row ? lane : 0;
+    const int m = part * kDimsPerWave + lane / W, il = lane % W;
+    const bool row = il < NP && m < kDMax;
+    const int i = il < NP ? il : 0, mm = m < kDMax ? m : 0;
     const double *sb = states + (size_t)s * StateBlock::size(NP);
     const double lam = row ? sb[StateBlock::lam(NP) + i] : 0.0, wi = row ? sb[StateBlock::wq(NP) + i] : 0.0;
     const int64_t rec0 = td.prefix_rec0 + ((int64_t)e * S + s) * T;
-    const int W = NP + 4;
-    double g[kDMax] = {0.0, 0.0, 0.0};
-    if (row)
-        for (int m = 0; m < kDMax; ++m) tail_g[((rec0 + (T - 1)) * kDMax + m) * NP + i] = 0.0; // g_{T-1} = 0
+    const int Wd = NP + 4;
+    double g = 0.0;
+    if (row) tail_g[((rec0 + (T - 1)) * kDMax + m) * NP + i] = 0.0; // g_{T-1} = 0
     if (T < 2) return;
-    const double *row_t = gain + (rec0 + (T - 1)) * W;
-    double K = row ? row_t[i] : 0.0, c0 = row_t[NP], c1 = row_t[NP + 1], c2 = row_t[NP + 2], obs = row_t[NP + kDMax];
-    for (int t = T - 1; t >= 1; --t) {
-        // (the numbers of frame t - 1 are on their way while frame t is worked on)
-        const double *nx = gain + (rec0 + (t > 1 ? t - 1 : 1)) * W;
-        const double Kn = row ? nx[i] : 0.0, c0n = nx[NP], c1n = nx[NP + 1], c2n = nx[NP + 2], obsn = nx[NP + kDMax];
-        if (obs != 0.0) {
-            double kg[kDMax];
-            for (int m = 0; m < kDMax; ++m) kg[m] = row ? K * g[m] : 0.0;
-            for (int m = 0; m < kDMax; ++m) kg[m] = wave_sum(kg[m]);
-            const double c[kDMax] = {c0, c1, c2};
-            for (int m = 0; m < kDMax; ++m) g[m] = lam * (g[m] - wi * kg[m]) + c[m] * lam * wi;
-        } else {
-            for (int m = 0; m < kDMax; ++m) g[m] *= lam;
+    // frames T - 1 ... 1 in chunks of kTailChunk; the chunk after this one is on its way while this one is worked on
+    double Kb[kTailChunk], cb[kTailChunk], ob[kTailChunk];
+    auto ask = [&](int t_hi, double *K, double *c, double *o) {
+#pragma unroll
+        for (int u = 0; u < kTailChunk; ++u) {
+            const int t = t_hi - u > 1 ? t_hi - u : 1;
+            const double *r = gain + (rec0 + t) * Wd;
+            K[u] = r[i];
+            c[u] = r[NP + mm];
+            o[u] = r[NP + kDMax];
         }
-        if (row)
-            for (int m = 0; m < kDMax; ++m) tail_g[((rec0 + (t - 1)) * kDMax + m) * NP + i] = g[m];
-        K = Kn;
-        c0 = c0n;
-        c1 = c1n;
-        c2 = c2n;
-        obs = obsn;
+    };
+    ask(T - 1, Kb, cb, ob);
+    for (int t_hi = T - 1; t_hi >= 1; t_hi -= kTailChunk) {
+        double Kn[kTailChunk], cn[kTailChunk], on[kTailChunk];
+        ask(t_hi - kTailChunk, Kn, cn, on);
+#pragma unroll
+        for (int u = 0; u < kTailChunk; ++u) {
+            const int t = t_hi - u;
+            if (t >= 1) {
+                if (ob[u] != 0.0) {
+                    double kg = row ? Kb[u] * g : 0.0;
+                    kg = row_sum16(kg);
+                    if constexpr (W == 32) kg += __shfl_xor(kg, 16, 64);
+                    g = lam * (g - wi * kg) + cb[u] * lam * wi;
+                } else {
+                    g *= lam;
+                }
+                if (row) tail_g[((rec0 + (t - 1)) * kDMax + m) * NP + i] = g;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kTailChunk; ++u) {
+            Kb[u] = Kn[u];
+            cb[u] = cn[u];
+            ob[u] = on[u];
+        }
     }
 }
 
@@ -147,7 +188,10 @@ int launch_tail(const TrajDesc *d_trajs, int n_traj, int S, int NP, int d, int d
     if (tasks <= 0 || total <= 0) return 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(tail_gain_kernel, dim3((unsigned)total), dim3(64), 0, st, d_trajs, n_traj, S, NP, d, dstar_max, d_states, d_prefix, d_first, d_gain);
-    hipLaunchKernelGGL(tail_scan_kernel, dim3((unsigned)tasks), dim3(64), 0, st, d_trajs, n_traj, S, NP, dstar_max, d_states, d_gain, d_tail_g);
+    if (NP <= 16)
+        hipLaunchKernelGGL(tail_scan_kernel<16>, dim3((unsigned)tasks), dim3(64), 0, st, d_trajs, n_traj, S, NP, dstar_max, d_states, d_gain, d_tail_g);
+    else // (two dimensions per wavefront: two wavefronts per task)
+        hipLaunchKernelGGL(tail_scan_kernel<32>, dim3((unsigned)(2 * tasks)), dim3(64), 0, st, d_trajs, n_traj, S, NP, dstar_max, d_states, d_gain, d_tail_g);
     return (int)hipGetLastError();
 }
 

@@ -26,7 +26,7 @@ def _frames(model, fn):
 @pytest.mark.parametrize('N,S,T,k,miss,err', [(20, 2, 1000, 4, 'none', 0.1), (20, 2, 1000, 8, 'none', 0.1), (20, 2, 600, 6, 'iid', 0.1),
                                               (20, 3, 800, 5, 'bursty', [0.1, 0.1, 0.3]), (32, 2, 1000, 4, 'none', 0.1),
                                               (24, 3, 700, 10, 'none', 0.1), (20, 3, 676, 7, 'none', 0.3),
-                                              (12, 2, 400, 12, 'none', 0.05)])
+                                              (12, 2, 400, 12, 'none', 0.05), (40, 2, 1500, 3, 'none', 0.1)])
 def test_tails_against_frame_by_frame(built_lib, N, S, T, k, miss, err):
     import bild_amd
     from bild_amd import _lib
