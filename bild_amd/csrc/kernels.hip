@@ -229,7 +229,11 @@ __device__ __forceinline__ void matvec_to_lds(XPtr X, const Cols<NP, CPL> &in, d
 // DUMP: this instantiation builds the prefix table (one per chain length is compiled, see launch_geom)
 // JUMP: this instantiation carries the machinery that takes frames out of the tables (convergence checks, transient table);
 // the frame-by-frame instantiation stays lean (the jump code costs registers the frame loop then spills around)
-template <int NP, int CPL, int G, int W, int OCC, int LAY, int MODE, int FLAVOR, bool DUMP, bool JUMP>
+// BUILD: the JUMP instantiation that builds the transient / pair / state tables (KParams::trans_dump, trans2_dump) -- and the only one
+// that can: what a builder needs (entries, state records) stays out of the evaluating kernels, and what they need (tails, walk plan,
+// landing on tables that do not exist yet) out of the builders.  (The tail code of round 4 cost the builders 70 % while it was
+// compiled into both: configs[3] tables 234 -> 406 ms.)
+template <int NP, int CPL, int G, int W, int OCC, int LAY, int MODE, int FLAVOR, bool DUMP, bool JUMP, bool BUILD>
 __device__ __forceinline__ void logl_body(const KParams &p)
 {
     constexpr bool HASG = FLAVOR == 0;
@@ -813,7 +817,9 @@ __device__ __forceinline__ void logl_body(const KParams &p)
         constexpr double kJumpTol = 1.1368683772161603e-13; // 2^-43
         const bool restore = !DUMP && p.prefix != nullptr;
         const bool jumping = JUMP && restore && !p.no_jump;
-        const bool building_transients = !kLean && jumping && (p.trans_dump != nullptr || p.trans2_dump != nullptr);
+        // (launch_geom: a BUILD instantiation is launched when, and only when, p.trans_dump or p.trans2_dump is set -- with the prefix
+        // table in place and jumps allowed)
+        constexpr bool building_transients = BUILD;
         const bool use_transients = jumping && p.trans != nullptr && !building_transients;
         auto record_of = [&](int st, int t) { return p.prefix + (td->prefix_rec0 + ((int64_t)e * S + st) * T + t) * REC; };
         auto record = [&](int t) { return record_of(s, t); };
@@ -1341,10 +1347,10 @@ __device__ __forceinline__ void logl_body(const KParams &p)
     }
 }
 
-template <int NP, int CPL, int G, int W, int OCC, int LAY, int MODE, int FLAVOR, bool DUMP = false, bool JUMP = false>
+template <int NP, int CPL, int G, int W, int OCC, int LAY, int MODE, int FLAVOR, bool DUMP = false, bool JUMP = false, bool BUILD = false>
 __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
 {
-    logl_body<NP, CPL, G, W, OCC, LAY, MODE, FLAVOR, DUMP, JUMP>(p);
+    logl_body<NP, CPL, G, W, OCC, LAY, MODE, FLAVOR, DUMP, JUMP, BUILD>(p);
 }
 
 __global__ void reduce_partials_kernel(const double *__restrict__ partial, double *__restrict__ out, int64_t n,
@@ -1409,6 +1415,17 @@ int launch_geom(int mode, const KParams &p, int grid, size_t lds, hipStream_t st
             if (flavor == 0) return go(logl_kernel<NP, CPL, G, W, OCC, LAY, kModal, 0, true>);
             if (flavor == 1) return go(logl_kernel<NP, CPL, G, W, OCC, LAY, kModal, 1, true>);
             return go(logl_kernel<NP, CPL, G, W, OCC, LAY, kModal, 2, true>);
+        } else {
+            return (int)hipErrorInvalidValue;
+        }
+    }
+    if (p.trans_dump || p.trans2_dump) {
+        // the transient / pair / state tables: the BUILD instantiation of the geometry (never the lean ones, see above)
+        if constexpr (LAY <= 2) {
+            if (mode != kModal || !p.prefix || p.no_jump) return (int)hipErrorInvalidValue;
+            if (flavor == 0) return go(logl_kernel<NP, CPL, G, W, OCC, LAY, kModal, 0, false, true, true>);
+            if (flavor == 1) return go(logl_kernel<NP, CPL, G, W, OCC, LAY, kModal, 1, false, true, true>);
+            return go(logl_kernel<NP, CPL, G, W, OCC, LAY, kModal, 2, false, true, true>);
         } else {
             return (int)hipErrorInvalidValue;
         }
