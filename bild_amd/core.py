@@ -28,6 +28,7 @@ def sample(traj, model,
            sampler_kw={},
            choice_kw={},
            show_progress=False,
+           driver='auto',
            ):
     """
     Run BILD on one trajectory (reference bild/core.py:22-236): AMIS samplers for k = 0, 1, ...
@@ -37,7 +38,28 @@ def sample(traj, model,
 
     Parameters and defaults are those of the reference.  Returns `SamplingResults` -- also on
     ``KeyboardInterrupt``, with whatever has been sampled so far.
+
+    ``driver`` (not in the reference): ``'python'`` runs the loop below, step by step in Python; ``'native'`` runs the same
+    loop inside the native inference driver (`sample_many`: same random numbers in the same order, same result bit for bit
+    -- tests/test_run.py, tests/test_gpu_run.py -- at a third to a half of the wall time per AMIS step); ``'auto'`` takes
+    the native driver where it applies without a change of behaviour: a plain `MultiStateRouse` model, the keywords
+    `sample_many` lists, no progress bar.
     """
+    if driver not in ('auto', 'native', 'python'):
+        raise ValueError("driver must be 'auto', 'native' or 'python'")
+    if driver != 'python':
+        plan, why = _native_plan(model, dict(dE=dE, init_runs=init_runs, certainty_in_k=certainty_in_k, k_lookahead=k_lookahead, k_max=k_max,
+                                             sampler_kw=sampler_kw, choice_kw=choice_kw, show_progress=show_progress))
+        if plan is not None and (driver == 'native' or plan['mode'] == 'gpu'):
+            return _sample_many_native([traj], model, False, plan, interruptible=True)[0]
+        if driver == 'native':
+            raise ValueError("the native inference driver does not apply: " + why)
+    return _sample_python(traj, model, dE, init_runs, certainty_in_k, k_lookahead, k_max, sampler_kw, choice_kw, show_progress)
+
+
+def _sample_python(traj, model, dE=0, init_runs=20, certainty_in_k=0.99, k_lookahead=2, k_max=20, sampler_kw={}, choice_kw={},
+                   show_progress=False):
+    """ `sample`, the loop in Python (what the reference runs) """
     run = _AdaptiveRun(make_trajectory(traj), model, dE, init_runs, certainty_in_k, k_lookahead, k_max,
                        dict(sampler_kw), dict(choice_kw), _progress_bar(show_progress))
     try:
@@ -250,8 +272,9 @@ def _per_k_constants(transitions, k_max, Nmax):
     return hit, out
 
 
-def _sample_many_native(trajs, model, return_exceptions, plan, rng=None):
-    """ `sample_many` through the native inference driver (see there) """
+def _sample_many_native(trajs, model, return_exceptions, plan, rng=None, interruptible=False):
+    """ `sample_many` through the native inference driver (see there); ``interruptible``: a KeyboardInterrupt between two
+        rounds ends the run with what has been sampled so far, as `sample` does """
     from . import _lib
     from .amis import FixedkSampler
     trajs = [make_trajectory(t) for t in trajs]
@@ -281,27 +304,31 @@ def _sample_many_native(trajs, model, return_exceptions, plan, rng=None):
     else:
         draw_gamma, draw_uniform, draw_normal = rng.standard_gamma, rng.random, rng.standard_normal
     failed_before = 0
-    while True:
-        counts, shapes = run.plan()
-        n_gamma, n_uniform, n_normal, n_rows, live = (int(v) for v in counts[:5])
-        if not return_exceptions and int(counts[6]) > failed_before:
-            raise_first_failure()
-        if n_rows == 0 and live == 0:
-            break
-        # the round's random numbers: three bulk draws from the global NumPy stream
-        gammas = draw_gamma(shapes) if n_gamma else np.empty(0)
-        uniforms = draw_uniform(n_uniform)
-        normals = draw_normal(n_normal)
-        if gpu:
-            run.round(handle, ts, gammas, uniforms, normals, path=model.path)
-        else:
-            ss, thetas, tid = run.stage(gammas, uniforms)
-            if len(tid):
-                seg_start, seg_state = _lib.segments_from_st(ss, thetas, T_arr[tid], n_states)
-                logLs = np.asarray(model.logL_segments(seg_start, seg_state, trajs, tid), dtype=np.float64)
+    try:
+        while True:
+            counts, shapes = run.plan()
+            n_gamma, n_uniform, n_normal, n_rows, live = (int(v) for v in counts[:5])
+            if not return_exceptions and int(counts[6]) > failed_before:
+                raise_first_failure()
+            if n_rows == 0 and live == 0:
+                break
+            # the round's random numbers: three bulk draws from the global NumPy stream
+            gammas = draw_gamma(shapes) if n_gamma else np.empty(0)
+            uniforms = draw_uniform(n_uniform)
+            normals = draw_normal(n_normal)
+            if gpu:
+                run.round(handle, ts, gammas, uniforms, normals, path=model.path)
             else:
-                logLs = np.empty(0)
-            run.finish(logLs, normals)
+                ss, thetas, tid = run.stage(gammas, uniforms)
+                if len(tid):
+                    seg_start, seg_state = _lib.segments_from_st(ss, thetas, T_arr[tid], n_states)
+                    logLs = np.asarray(model.logL_segments(seg_start, seg_state, trajs, tid), dtype=np.float64)
+                else:
+                    logLs = np.empty(0)
+                run.finish(logLs, normals)
+    except KeyboardInterrupt:  # pragma: no cover
+        if not interruptible:
+            raise
     results = []
     for j, traj in enumerate(trajs):
         state, kind, n_samplers, n_rows, width, message = run.traj_info(j)

@@ -26,11 +26,17 @@ def test_one_trajectory_native_equals_python_on_gpu(built_lib):
     model = bild_amd.MultiStateRouse(20, 1, 5, d=3, localization_error=0.1)
     for j, traj in enumerate(_trajs(model, rng, 3)):
         np.random.seed(100 + j)
-        ref = bild_amd.sample(traj, model)
+        ref = bild_amd.sample(traj, model, driver='python')
         after_ref = np.random.random_sample()
         np.random.seed(100 + j)
         got = bild_amd.sample_many([traj], model, driver='native')[0]
         after_got = np.random.random_sample()
+        np.random.seed(100 + j)
+        auto = bild_amd.sample(traj, model)             # 'auto': the native driver for this model and these keywords
+        assert np.random.random_sample() == after_ref
+        assert np.array_equal(ref.log['k'], auto.log['k']) and np.array_equal(ref.evidence, auto.evidence)
+        assert np.array_equal(ref.best_profile()[:], auto.best_profile()[:])
+        assert auto.samplers[-1]._adopted                # (it did come out of the native driver)
         assert after_ref == after_got
         assert np.array_equal(ref.log['k'], got.log['k'])
         assert np.array_equal(ref.evidence, got.evidence) and np.array_equal(ref.evidence_se, got.evidence_se)

@@ -109,7 +109,7 @@ def test_one_trajectory_is_the_python_loop_bit_for_bit(case):
     for j, traj in enumerate(trajs):
         for seed in (5, 6):
             np.random.seed(seed + 10 * j)
-            ref = bild_amd.sample(traj, model, **kw)
+            ref = bild_amd.sample(traj, model, driver='python', **kw)
             after_ref = np.random.random_sample()
             np.random.seed(seed + 10 * j)
             got = bild_amd.sample_many([traj], model, driver='native', **kw)[0]
@@ -127,7 +127,7 @@ def test_three_states_and_restricted_transitions():
     kw = dict(init_runs=3, k_max=4, sampler_kw={'N': 24, 'max_fev': 500, 'max_fcomplete': 40}, choice_kw={'samplesize': 400})
     for j, traj in enumerate(trajs):
         np.random.seed(j)
-        ref = bild_amd.sample(traj, model, **kw)
+        ref = bild_amd.sample(traj, model, driver='python', **kw)
         np.random.seed(j)
         got = bild_amd.sample_many([traj], model, driver='native', **kw)[0]
         _same_result(ref, got)
@@ -139,7 +139,7 @@ def test_tiny_trajectories_and_refusals():
     for j, T in ((0, 1), (1, 3)):
         traj = bild_amd.Trajectory(np.full((T, 1), float(j)))
         np.random.seed(1)
-        ref = bild_amd.sample(traj, model, k_max=5)
+        ref = bild_amd.sample(traj, model, k_max=5, driver='python')
         np.random.seed(1)
         got = bild_amd.sample_many([traj], model, driver='native', k_max=5)[0]
         _same_result(ref, got)
@@ -193,7 +193,7 @@ def test_adopted_samplers_go_on_pickle_and_copy():
     model = RoutedTables(tables)
     kw = dict(init_runs=3, k_max=3, sampler_kw={'N': 20, 'max_fev': 10 ** 6, 'max_fcomplete': 30}, choice_kw={'samplesize': 300})
     np.random.seed(9)
-    ref = bild_amd.sample(trajs[1], model, **kw)
+    ref = bild_amd.sample(trajs[1], model, driver='python', **kw)
     np.random.seed(9)
     got = bild_amd.sample_many([trajs[1]], model, driver='native', **kw)[0]
     k = max(s.k for s in got.samplers if not s.exhausted)
@@ -251,3 +251,25 @@ def test_a_numpy_generator_as_the_source_of_random_numbers():
     assert all(np.all(np.isfinite(r.evidence[:2])) for r in a)
     with pytest.raises(ValueError, match="native inference driver only"):
         bild_amd.sample_many(trajs, model, driver='python', rng=np.random.default_rng(3), **kw)
+
+
+def test_sample_takes_the_driver_it_is_told():
+    """ `sample(..., driver=)`: 'native' is `sample_many([traj])[0]`, 'auto' stays in Python for a model that is no plain
+        MultiStateRouse, a request the native driver cannot serve is refused when it is asked for by name """
+    tables, trajs = _problem(2)
+    model = RoutedTables(tables)
+    kw = CASES['one_init_run']
+    np.random.seed(3)
+    ref = bild_amd.sample(trajs[0], model, driver='python', **kw)
+    np.random.seed(3)
+    got = bild_amd.sample(trajs[0], model, driver='native', **kw)
+    _same_result(ref, got)
+    assert got.samplers[-1]._adopted
+    np.random.seed(3)
+    auto = bild_amd.sample(trajs[0], model, **kw)
+    _same_result(ref, auto)
+    assert not getattr(auto.samplers[-1], '_adopted', False)
+    with pytest.raises(ValueError):
+        bild_amd.sample(trajs[0], model, driver='fastest')
+    with pytest.raises(ValueError):
+        bild_amd.sample(trajs[0], model, driver='native', show_progress=True)
