@@ -14,7 +14,7 @@ struct Config {
     bool no_transients = false;  // BILD_NO_TRANSIENTS    no transient table
     bool no_pairs = false;       // BILD_NO_PAIRS         no pair table
     bool no_states = false;      // BILD_NO_STATES        no transient state table
-    int tail_tol_bits = 24;      // BILD_TAIL_TOL_BITS    first-order tail: mean columns within 2^-bits of the table's
+    int tail_tol_bits = 20;      // BILD_TAIL_TOL_BITS    first-order tail: mean columns within 2^-bits of the table's
     int tail_margin = 8;         // BILD_TAIL_MARGIN      ... and the next switch this many frames beyond the table's own transient
     bool no_tail = false;        // BILD_NO_TAIL          no first-order tails: a transient runs until its means have converged too
     int64_t states_max_bytes = -1;                // BILD_STATES_MAX_BYTES  (-1: 4 GB, 64 GB for sets declared for >= 1e8 evaluations)

@@ -1124,8 +1124,8 @@ __device__ __forceinline__ void logl_body(const KParams &p)
             double excess = 0.0;
             bool same = true;
             // first-order tail (tail.hip): the covariance columns must have converged as before; a mean column may still be
-            // kTailTol = 2^-24 away -- what that deviation does to every later frame is a dot product with the table's g
-            const double kTailTol = p.tail_tol;  // (2^-24 unless BILD_TAIL_TOL_BITS says otherwise)
+            // kTailTol = 2^-20 away -- what that deviation does to every later frame is a dot product with the table's g
+            const double kTailTol = p.tail_tol;  // (2^-20 unless BILD_TAIL_TOL_BITS says otherwise: tools/tail_tolerance.py)
             const int kTailMargin = p.tail_margin; // frames beyond the table's own transient before the next switch may come (8)
             const bool tails = JUMP && p.tail_g != nullptr && !building_transients;
             bool near = true;

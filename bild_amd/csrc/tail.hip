@@ -14,7 +14,7 @@
 // (kDMax x NP doubles, beside the table: KParams::tail_g) -- in two kernels: what it needs of the table's filter at every frame
 // (gain, innovations) is recomputed for all frames in parallel, the pass that is sequential in t then moves one double per
 // lane and frame (3.1 ms per T = 1000 trajectory in one kernel that did both -> 0.8 ms in two -> see tail_scan_kernel).  The frame loop then leaves a transient as
-// soon as its covariance has converged and its means are within 2^-24 of the table's (delta^2 terms < 1e-13), adds
+// soon as its covariance has converged and its means are within 2^-20 of the table's (delta^2 terms ~ 1e-11 at the bound, 1e-12 in the runs), adds
 // g . delta, and takes the table's sums for the rest of the segment -- if the next switch is far enough away for the means
 // to have converged by then (kernels.hip: compare_with_table).  NumPy experiment behind it (default model, N = 20 / 32): jump
 // after 17-21 / 75 frames instead of 36-46 / 89-111, remaining log-likelihood reproduced to 2-4e-13.

@@ -84,7 +84,7 @@ typedef enum bild_status {
 /* Do not leave a transient on the first-order tail (csrc/tail.hip: once the covariance of a candidate's filter has converged
  * onto the switch-free filter's, the effect of the remaining deviation of the means on all later frames is a dot product with
  * a vector kept beside the prefix table): every transient runs until its means have converged too, as until round 3.  The
- * results differ by ~1e-12 (second-order terms of a deviation below 2^-24).  (Environment BILD_NO_TAIL=1: never build the vectors.) */
+ * results differ by ~1e-12 (second-order terms of a deviation below 2^-20).  (Environment BILD_NO_TAIL=1: never build the vectors.) */
 #define BILD_NO_TAIL 0x200u
 
 /* bild_model_create flags */
