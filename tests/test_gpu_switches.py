@@ -18,19 +18,20 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-8
 SWITCHES = ['BILD_NO_SPLIT', 'BILD_NO_STATES', 'BILD_NO_LISTED_GEOMETRY', 'BILD_NO_PAIRS', 'BILD_NO_TRANSIENTS', 'BILD_NO_JUMP',
             'BILD_NO_PREFIX', 'BILD_NO_WALK_PLAN', 'BILD_NO_FUSED_LAUNCH', 'BILD_NO_SPLIT+BILD_NO_STATES',
-            'BILD_NO_LISTED_GEOMETRY+BILD_NO_STATES']
+            'BILD_NO_LISTED_GEOMETRY+BILD_NO_STATES', 'BILD_NO_TAIL', 'BILD_NO_TAIL+BILD_NO_STATES', 'BILD_TAIL_TOL_BITS=24',
+            'BILD_TAIL_MARGIN=0', 'BILD_STATES_STRIDE=1', 'BILD_STATES_MAX_GAP=16', 'BILD_STATES_MAX_BYTES=1000000']
 
 
 @pytest.fixture
 def switch(request, built_lib):
     from bild_amd import _lib
-    names = request.param.split('+')
-    for name in names:
-        os.environ[name] = '1'
+    settings = [(item.split('=') + ['1'])[:2] for item in request.param.split('+')]      # NAME or NAME=value
+    for name, value in settings:
+        os.environ[name] = value
     _lib.config_reload()
-    assert all(f'{name}=1' in _lib.config_string().split() for name in names)
+    assert all(f'{name}={value}' in _lib.config_string().split() for name, value in settings)
     yield request.param
-    for name in names:
+    for name, _ in settings:
         del os.environ[name]
     _lib.config_reload()
 
