@@ -41,7 +41,7 @@ def sample(traj, model,
 
     ``driver`` (not in the reference): ``'python'`` runs the loop below, step by step in Python; ``'native'`` runs the same
     loop inside the native inference driver (`sample_many`: same random numbers in the same order, same result bit for bit
-    -- tests/test_run.py, tests/test_gpu_run.py -- at a third to a half of the wall time per AMIS step); ``'auto'`` takes
+    -- tests/test_run.py, tests/test_gpu_run.py -- at half to three quarters of the wall time per AMIS step); ``'auto'`` takes
     the native driver where it applies without a change of behaviour: a plain `MultiStateRouse` model, the keywords
     `sample_many` lists, no progress bar.
     """
