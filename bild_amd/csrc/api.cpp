@@ -11,7 +11,9 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <map>
 #include <mutex>
+#include <unordered_map>
 #include <queue>
 #include <new>
 #include <string>
@@ -87,6 +89,87 @@ struct DeviceBuf {
         cap = 0;
     }
 };
+
+// Table memory is recycled.  hipFree of a block of two megabytes or more unmaps it -- 0.22 ms a piece, whatever its size: 0.9 ms per
+// trajectory set between the scratch of its builders and its three large tables, a tenth of what `sample` spends on an ordinary
+// trajectory when they come one after the other (rocprofv3 --hip-trace of tools/first_call.py).  Blocks of 128 KiB and more are therefore
+// rounded up to a size class (powers of two in quarter steps) and kept for the next trajectory set when they are released -- up to
+// BILD_TABLE_CACHE_BYTES (default 4 GB; 0: every block goes back to the driver at once).  A request that cannot be met flushes the cache
+// and asks again.  Nothing is returned at process exit (the runtime may be gone by then).
+struct TableCache {
+    std::mutex mu;
+    std::multimap<size_t, void *> idle;         // size class -> block
+    std::unordered_map<void *, size_t> classes; // every block handed out or idle that came from here
+    size_t held = 0;
+    static size_t size_class(size_t bytes)
+    {
+        size_t c = (size_t)128 << 10;
+        while (c < bytes) {
+            const size_t q = c / 4;
+            for (int k = 1; k <= 4 && c < bytes; ++k) c += q; // c, 1.25 c, 1.5 c, 1.75 c, 2 c
+        }
+        return c;
+    }
+    void flush_locked()
+    {
+        for (auto &kv : idle) {
+            classes.erase(kv.second);
+            (void)hipFree(kv.second);
+        }
+        idle.clear();
+        held = 0;
+    }
+};
+TableCache g_tables;
+
+hipError_t tab_malloc(void **out, size_t bytes)
+{
+    *out = nullptr;
+    const int64_t cap = config().table_cache_bytes;
+    if (cap <= 0 || bytes < ((size_t)128 << 10)) return hipMalloc(out, bytes);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const size_t bytes_cls = TableCache::size_class(bytes);
+    const size_t cls = bytes_cls | ((size_t)dev << 56); // (blocks stay on the device they were made on)
+    std::lock_guard<std::mutex> lk(g_tables.mu);
+    auto it = g_tables.idle.find(cls);
+    if (it != g_tables.idle.end()) {
+        *out = it->second;
+        g_tables.held -= bytes_cls;
+        g_tables.idle.erase(it);
+        return hipSuccess;
+    }
+    hipError_t e = hipMalloc(out, bytes_cls);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        g_tables.flush_locked();
+        e = hipMalloc(out, bytes_cls);
+    }
+    if (e == hipSuccess) g_tables.classes[*out] = cls;
+    return e;
+}
+
+void tab_free(void *ptr)
+{
+    if (!ptr) return;
+    std::unique_lock<std::mutex> lk(g_tables.mu);
+    auto it = g_tables.classes.find(ptr);
+    if (it == g_tables.classes.end()) { // (a small block, or the cache is off)
+        lk.unlock();
+        (void)hipFree(ptr);
+        return;
+    }
+    const size_t cls = it->second, bytes_cls = cls & (((size_t)1 << 56) - 1);
+    const int64_t cap = config().table_cache_bytes;
+    if (cap > 0 && g_tables.held + bytes_cls <= (size_t)cap) {
+        g_tables.idle.emplace(cls, ptr);
+        g_tables.held += bytes_cls;
+        return;
+    }
+    g_tables.classes.erase(it);
+    lk.unlock();
+    (void)hipFree(ptr);
+}
 
 // page-locked host staging: copies to and from it are true asynchronous DMA transfers
 struct PinnedBuf {
@@ -672,16 +755,16 @@ int ensure_prefix(const bild_model &m, const bild_trajset &ts, hipStream_t st)
     int32_t *d_desc = nullptr;
     double *d_tab = nullptr, *d_sink = nullptr, *d_L = nullptr;
     auto cleanup = [&](bool keep) {
-        if (d_desc) (void)hipFree(d_desc);
-        if (d_sink) (void)hipFree(d_sink);
-        if (!keep && d_tab) (void)hipFree(d_tab);
-        if (!keep && d_L) (void)hipFree(d_L);
+        if (d_desc) tab_free(d_desc);
+        if (d_sink) tab_free(d_sink);
+        if (!keep && d_tab) tab_free(d_tab);
+        if (!keep && d_L) tab_free(d_L);
     };
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    bool ok = hipMalloc((void **)&d_desc, host.size() * sizeof(int32_t)) == hipSuccess &&
-              hipMalloc((void **)&d_sink, (size_t)nb * ts.dstar_max * sizeof(double)) == hipSuccess &&
-              hipMalloc((void **)&d_tab, bytes) == hipSuccess &&
-              hipMalloc((void **)&d_L, (size_t)ts.prefix_records * sizeof(double)) == hipSuccess &&
+    bool ok = tab_malloc((void **)&d_desc, host.size() * sizeof(int32_t)) == hipSuccess &&
+              tab_malloc((void **)&d_sink, (size_t)nb * ts.dstar_max * sizeof(double)) == hipSuccess &&
+              tab_malloc((void **)&d_tab, bytes) == hipSuccess &&
+              tab_malloc((void **)&d_L, (size_t)ts.prefix_records * sizeof(double)) == hipSuccess &&
               hipMemsetAsync(d_L, 0, (size_t)ts.prefix_records * sizeof(double), st) == hipSuccess &&
               hipMemcpy(d_desc, host.data(), host.size() * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess &&
               hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
@@ -719,9 +802,9 @@ int ensure_prefix(const bild_model &m, const bild_trajset &ts, hipStream_t st)
         std::vector<int64_t> first((size_t)ts.n_traj + 1, 0); // blocks of the parallel phase, trajectory by trajectory
         for (int j = 0; j < ts.n_traj; ++j) first[(size_t)j + 1] = first[j] + (int64_t)ts.dstar_max * S * ts.descs[j].T;
         bool good = first.back() == ts.prefix_records && first.back() < ((int64_t)1 << 31) &&
-                    hipMalloc((void **)&d_g, gbytes) == hipSuccess &&
-                    hipMalloc((void **)&d_gain, (size_t)ts.prefix_records * (NP + 4) * sizeof(double)) == hipSuccess &&
-                    hipMalloc((void **)&d_first, first.size() * sizeof(int64_t)) == hipSuccess &&
+                    tab_malloc((void **)&d_g, gbytes) == hipSuccess &&
+                    tab_malloc((void **)&d_gain, (size_t)ts.prefix_records * (NP + 4) * sizeof(double)) == hipSuccess &&
+                    tab_malloc((void **)&d_first, first.size() * sizeof(int64_t)) == hipSuccess &&
                     hipMemcpy(d_first, first.data(), first.size() * sizeof(int64_t), hipMemcpyHostToDevice) == hipSuccess &&
                     hipEventCreate(&t0) == hipSuccess && hipEventCreate(&t1) == hipSuccess;
         if (good) {
@@ -734,12 +817,12 @@ int ensure_prefix(const bild_model &m, const bild_trajset &ts, hipStream_t st)
         }
         if (t0) (void)hipEventDestroy(t0);
         if (t1) (void)hipEventDestroy(t1);
-        if (d_gain) (void)hipFree(d_gain);
-        if (d_first) (void)hipFree(d_first);
+        if (d_gain) tab_free(d_gain);
+        if (d_first) tab_free(d_first);
         if (good) {
             ts.d_tail_g = d_g;
         } else {
-            if (d_g) (void)hipFree(d_g);
+            if (d_g) tab_free(d_g);
             (void)hipGetLastError();
         }
     }
@@ -804,9 +887,9 @@ int ensure_transients(const bild_model &m, const bild_trajset &ts, hipStream_t s
     double *d_sink = nullptr;
     TransEntry *d_tab = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    bool ok = hipMalloc((void **)&d_desc, host.size() * sizeof(int32_t)) == hipSuccess &&
-              hipMalloc((void **)&d_sink, (size_t)nb * sizeof(double)) == hipSuccess &&
-              hipMalloc((void **)&d_tab, bytes) == hipSuccess && hipMemsetAsync(d_tab, 0, bytes, st) == hipSuccess &&
+    bool ok = tab_malloc((void **)&d_desc, host.size() * sizeof(int32_t)) == hipSuccess &&
+              tab_malloc((void **)&d_sink, (size_t)nb * sizeof(double)) == hipSuccess &&
+              tab_malloc((void **)&d_tab, bytes) == hipSuccess && hipMemsetAsync(d_tab, 0, bytes, st) == hipSuccess &&
               hipMemcpy(d_desc, host.data(), host.size() * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess &&
               hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
     // First launch: the entries alone.  How long transients last is not known before it has run, and the state table beside
@@ -885,7 +968,7 @@ int ensure_transients(const bild_model &m, const bild_trajset &ts, hipStream_t s
         }
         const size_t sbytes = (size_t)snq * per_q;
         if (snq > 0) {
-            if (hipMalloc((void **)&d_states, sbytes) != hipSuccess) {
+            if (tab_malloc((void **)&d_states, sbytes) != hipSuccess) {
                 d_states = nullptr;
                 (void)hipGetLastError();
             }
@@ -896,7 +979,7 @@ int ensure_transients(const bild_model &m, const bild_trajset &ts, hipStream_t s
             ts.snq = snq;
             ts.strans_records = ts.strans_entries * snq;
             if (!build_pass(d_states)) { // (the entries are complete; only the state table is lost)
-                (void)hipFree(d_states);
+                tab_free(d_states);
                 d_states = nullptr;
                 ts.strans_records = 0;
                 (void)hipGetLastError();
@@ -906,15 +989,15 @@ int ensure_transients(const bild_model &m, const bild_trajset &ts, hipStream_t s
     ts.trans_build_ms = ms_total;
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
-    if (d_desc) (void)hipFree(d_desc);
-    if (d_sink) (void)hipFree(d_sink);
+    if (d_desc) tab_free(d_desc);
+    if (d_sink) tab_free(d_sink);
     if (ok) {
         ts.d_trans = d_tab;
         ts.d_strans = d_states;
         ts.trans_state = 1;
     } else {
-        if (d_tab) (void)hipFree(d_tab);
-        if (d_states) (void)hipFree(d_states);
+        if (d_tab) tab_free(d_tab);
+        if (d_states) tab_free(d_states);
         (void)hipGetLastError();
     }
     return BILD_OK;
@@ -957,10 +1040,10 @@ int ensure_pairs(const bild_model &m, const bild_trajset &ts, hipStream_t st)
     double *d_sink = nullptr;
     TransEntry *d_tab = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    bool ok = hipMalloc((void **)&d_desc, (size_t)7 * nb * sizeof(int32_t)) == hipSuccess &&
-              hipMalloc((void **)&d_first, first.size() * sizeof(int64_t)) == hipSuccess &&
-              hipMalloc((void **)&d_sink, (size_t)nb * sizeof(double)) == hipSuccess &&
-              hipMalloc((void **)&d_tab, bytes) == hipSuccess && hipMemsetAsync(d_tab, 0, bytes, st) == hipSuccess &&
+    bool ok = tab_malloc((void **)&d_desc, (size_t)7 * nb * sizeof(int32_t)) == hipSuccess &&
+              tab_malloc((void **)&d_first, first.size() * sizeof(int64_t)) == hipSuccess &&
+              tab_malloc((void **)&d_sink, (size_t)nb * sizeof(double)) == hipSuccess &&
+              tab_malloc((void **)&d_tab, bytes) == hipSuccess && hipMemsetAsync(d_tab, 0, bytes, st) == hipSuccess &&
               hipMemcpyAsync(d_first, first.data(), first.size() * sizeof(int64_t), hipMemcpyHostToDevice, st) == hipSuccess &&
               launch_pair_tasks(d_first, ts.n_traj, ts.d_descs, S, G, nb, d_desc, d_desc + 3 * nb, d_desc + 6 * nb, (void *)st) == 0 &&
               hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
@@ -981,9 +1064,9 @@ int ensure_pairs(const bild_model &m, const bild_trajset &ts, hipStream_t st)
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
     if (!ok) (void)hipStreamSynchronize(st); // (`first` is read by an asynchronous copy)
-    if (d_desc) (void)hipFree(d_desc);
-    if (d_first) (void)hipFree(d_first);
-    if (d_sink) (void)hipFree(d_sink);
+    if (d_desc) tab_free(d_desc);
+    if (d_first) tab_free(d_first);
+    if (d_sink) tab_free(d_sink);
     if (ok) {
         // do the tables cover every candidate of at most two switches?  (schedule.hip: two_switch_cover_kernel)
         std::vector<int64_t> ent((size_t)ts.n_traj + 1, 0);
@@ -992,20 +1075,20 @@ int ensure_pairs(const bild_model &m, const bild_trajset &ts, hipStream_t st)
         int64_t *d_ent = nullptr;
         int *d_cov = nullptr;
         int cov = 1;
-        const bool good = hipMalloc((void **)&d_ent, ent.size() * sizeof(int64_t)) == hipSuccess && hipMalloc((void **)&d_cov, sizeof(int)) == hipSuccess &&
+        const bool good = tab_malloc((void **)&d_ent, ent.size() * sizeof(int64_t)) == hipSuccess && tab_malloc((void **)&d_cov, sizeof(int)) == hipSuccess &&
                           hipMemcpy(d_ent, ent.data(), ent.size() * sizeof(int64_t), hipMemcpyHostToDevice) == hipSuccess &&
                           hipMemcpy(d_cov, &cov, sizeof(int), hipMemcpyHostToDevice) == hipSuccess &&
                           launch_two_switch_cover(ts.d_descs, d_ent, ent.back(), ts.n_traj, S, ts.d_trans, d_tab, G, d_cov, (void *)st) == 0 &&
                           hipStreamSynchronize(st) == hipSuccess && hipMemcpy(&cov, d_cov, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
-        if (d_ent) (void)hipFree(d_ent);
-        if (d_cov) (void)hipFree(d_cov);
+        if (d_ent) tab_free(d_ent);
+        if (d_cov) tab_free(d_cov);
         if (!good) (void)hipGetLastError();
         ts.two_switch_covered = good && cov == 1 ? 1 : 0;
         ts.d_trans2 = d_tab;
         ts.trans2_entries = entries;
         ts.trans2_state = 1;
     } else {
-        if (d_tab) (void)hipFree(d_tab);
+        if (d_tab) tab_free(d_tab);
         (void)hipGetLastError();
     }
     return BILD_OK;
@@ -1954,12 +2037,12 @@ int bild_trajset_destroy(bild_trajset *ts)
     if (!ts) return BILD_OK;
     if (ts->d_x) (void)hipFree(ts->d_x);
     if (ts->d_descs) (void)hipFree(ts->d_descs);
-    if (ts->d_prefix) (void)hipFree(ts->d_prefix);
-    if (ts->d_prefix_L) (void)hipFree(ts->d_prefix_L);
-    if (ts->d_tail_g) (void)hipFree(ts->d_tail_g);
-    if (ts->d_trans) (void)hipFree(ts->d_trans);
-    if (ts->d_trans2) (void)hipFree(ts->d_trans2);
-    if (ts->d_strans) (void)hipFree(ts->d_strans);
+    tab_free(ts->d_prefix);
+    tab_free(ts->d_prefix_L);
+    tab_free(ts->d_tail_g);
+    tab_free(ts->d_trans);
+    tab_free(ts->d_trans2);
+    tab_free(ts->d_strans);
     delete ts;
     return BILD_OK;
 }

@@ -41,6 +41,7 @@ void load(Config &c)
     flag("BILD_NO_PAIRS", c.no_pairs);
     flag("BILD_NO_STATES", c.no_states);
     flag("BILD_NO_TAIL", c.no_tail);
+    num("BILD_TABLE_CACHE_BYTES", c.table_cache_bytes);
     num("BILD_TAIL_TOL_BITS", c.tail_tol_bits);
     num("BILD_TAIL_MARGIN", c.tail_margin);
     num("BILD_STATES_MAX_BYTES", c.states_max_bytes);

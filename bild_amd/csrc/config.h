@@ -16,6 +16,7 @@ struct Config {
     bool no_states = false;      // BILD_NO_STATES        no transient state table
     int tail_tol_bits = 20;      // BILD_TAIL_TOL_BITS    first-order tail: mean columns within 2^-bits of the table's
     int tail_margin = 8;         // BILD_TAIL_MARGIN      ... and the next switch this many frames beyond the table's own transient
+    int64_t table_cache_bytes = (int64_t)4 << 30; // BILD_TABLE_CACHE_BYTES  table memory kept for the next trajectory set (0: none)
     bool no_tail = false;        // BILD_NO_TAIL          no first-order tails: a transient runs until its means have converged too
     int64_t states_max_bytes = -1;                // BILD_STATES_MAX_BYTES  (-1: 4 GB, 64 GB for sets declared for >= 1e8 evaluations)
     int states_max_gap = 128;                     // BILD_STATES_MAX_GAP    largest gap the state table covers (<= 255; 64 until round 4)

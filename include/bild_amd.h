@@ -174,6 +174,9 @@ int bild_model_export(const bild_model *m, int what, int s, int s2, double *buf,
  */
 int bild_trajset_create(const bild_model *m, int n_traj, const int32_t *T,
                         const double *x, const double *loc_err, bild_trajset **out);
+/* (The device memory of a set's tables -- blocks of 128 KiB and more -- is not returned to the driver but kept, in size classes, for the
+ * tables of the next set: up to BILD_TABLE_CACHE_BYTES, default 4 GB per process; 0 turns that off.  No evaluation on the set may be in
+ * flight when it is destroyed.) */
 int bild_trajset_destroy(bild_trajset *ts);
 /* Optional, before the first evaluation on the set: how many evaluations the caller expects to run on it in total.  The
  * tables of a set (see "prefix table" below) are built at its first evaluation and cost about 2 ms per trajectory of

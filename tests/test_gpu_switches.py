@@ -19,7 +19,8 @@ TOL = 1e-8
 SWITCHES = ['BILD_NO_SPLIT', 'BILD_NO_STATES', 'BILD_NO_LISTED_GEOMETRY', 'BILD_NO_PAIRS', 'BILD_NO_TRANSIENTS', 'BILD_NO_JUMP',
             'BILD_NO_PREFIX', 'BILD_NO_WALK_PLAN', 'BILD_NO_FUSED_LAUNCH', 'BILD_NO_SPLIT+BILD_NO_STATES',
             'BILD_NO_LISTED_GEOMETRY+BILD_NO_STATES', 'BILD_NO_TAIL', 'BILD_NO_TAIL+BILD_NO_STATES', 'BILD_TAIL_TOL_BITS=24',
-            'BILD_TAIL_MARGIN=0', 'BILD_STATES_STRIDE=1', 'BILD_STATES_MAX_GAP=16', 'BILD_STATES_MAX_BYTES=1000000']
+            'BILD_TAIL_MARGIN=0', 'BILD_STATES_STRIDE=1', 'BILD_STATES_MAX_GAP=16', 'BILD_STATES_MAX_BYTES=1000000',
+            'BILD_TABLE_CACHE_BYTES=0']
 
 
 @pytest.fixture
