@@ -782,7 +782,8 @@ int ensure_prefix(const bild_model &m, const bild_trajset &ts, hipStream_t st)
         const int64_t tpb = (int64_t)geom.W * geom.tasks_per_wave();
         const int grid = (int)std::min<int64_t>(std::max<int64_t>((p.ntasks + tpb - 1) / tpb, 1), 256 * 16);
         (void)hipEventRecord(e0, st);
-        ok = launch_logl(geom, kModal, p, grid, lds, (void *)st) == 0;
+        ok = launch_logl(geom, kModal, p, grid, lds, (void *)st) == 0 &&
+             launch_prefix_L(ts.d_descs, ts.n_traj, S, NP, ts.dstar_max, ts.Tmax, d_tab, d_L, (void *)st) == 0; // (the records' running log-likelihoods)
         (void)hipEventRecord(e1, st);
         ok = ok && hipStreamSynchronize(st) == hipSuccess;
         float ms = 0.f;

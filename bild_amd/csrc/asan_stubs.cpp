@@ -18,6 +18,7 @@ bool geometry_for(int, int, int64_t, int, Geometry *) { return false; }
 const char *kernel_name(const Geometry &, int) { return "none"; }
 int launch_logl(const Geometry &, int, const KParams &, int, size_t, void *, void *, void *) { return 1; }
 int launch_reduce_partials(const double *, double *, int64_t, int, void *) { return 1; }
+int launch_prefix_L(const TrajDesc *, int, int, int, int, int, double *, double *, void *) { return 1; }
 int launch_validate(const int32_t *, const int32_t *, const int32_t *, const int32_t *, int64_t, int, int, int, int *, void *) { return 1; }
 bool builder_geometry(int, Geometry *) { return false; }
 bool listed_geometry(const Geometry &, Geometry *) { return false; }

@@ -216,6 +216,7 @@ constexpr int kWalkDoubles = 3 * kSegLds;
 int launch_logl(const Geometry &g, int mode, const KParams &p, int grid, size_t lds_bytes, void *stream, void *ev_start = nullptr,
                 void *ev_stop = nullptr);
 int launch_reduce_partials(const double *partial, double *out, int64_t n, int dstar_max, void *stream);
+int launch_prefix_L(const TrajDesc *d_trajs, int n_traj, int S, int NP, int dstar_max, int Tmax, double *d_prefix, double *d_prefix_L, void *stream);
 // d_err: 2 ints (verdict, a sample that shows it) followed, when `order` is given, by n hit counters; zeroed by the caller
 int launch_validate(const int32_t *seg_start, const int32_t *seg_state, const int32_t *traj_id, const int32_t *order, int64_t n,
                     int K1, int S, int n_traj, int *d_err, void *stream);

@@ -126,6 +126,16 @@ struct RowOps<NP, NP> {
 // out of the task loop into registers the frame loop then has to spill around.
 __device__ __attribute__((noinline)) double log_once(double x) { return log(x); }
 
+// The log-likelihood of a piece from its sums: tot = sum over the dimensions of sum_t e_t^2 / S_t, the product of the S_t as P x 2^E, nv
+// observed frames, nd dimensions (reference bild/src/MSRouse_logL.pyx:250-254 summed over frames).  One place for the arithmetic of
+// the task loop (piece_value) and of the pass that fills the running log-likelihoods of the prefix table (prefix_L_kernel).
+__device__ __forceinline__ double piece_from_sums(double tot, double P, int E, int nv, int nd)
+{
+    const double logS = log_once(P) + (double)E * kLn2;
+    tot += (double)nd * (logS + (double)nv * kLog2Pi);
+    return -0.5 * tot;
+}
+
 template <int NP, int CPL>
 struct Cols {
     double v[CPL][NP];
@@ -851,9 +861,7 @@ __device__ __forceinline__ void logl_body(const KParams &p)
 #pragma unroll
             for (int g2 = 0; g2 < G; ++g2) tot += scratch[g2];
             wave_lds_fence();
-            const double logS = log_once(P) + (double)E * kLn2;
-            tot += (double)nd * (logS + (double)nv * kLog2Pi);
-            return -0.5 * tot;
+            return piece_from_sums(tot, P, E, nv, nd);
         };
         // sum of one value per lane over the lanes of the task, in lane order (the same in every lane of the task)
         auto group_sum = [&](double v) {
@@ -1077,14 +1085,13 @@ __device__ __forceinline__ void logl_body(const KParams &p)
                 }
                 if (isM[q]) rec[NC * NP + (cidx[q] - NP)] = accq[q];
             }
-            const double Lsofar = piece_value(); // running log-likelihood of the switch-free filter
+            // (the running log-likelihood of the switch-free filter, kRecL and its dense copy, is filled in behind this launch from
+            // the sums stored here -- prefix_L_kernel, one thread per record: computed here it was a logarithm and an LDS round
+            // trip in every frame of a launch that is two wavefronts per trajectory, a quarter of the builder's 0.94 us per frame)
             if (gl == 0) {
                 rec[kRecP] = P;
                 rec[kRecE] = (double)E;
-                rec[kRecL] = Lsofar;
                 rec[kRecNv] = (double)nv;
-                // ... and once more, densely: the table walk (walk.hip) reads nothing else of a record
-                if (p.prefix_L_dump) p.prefix_L_dump[td->prefix_rec0 + ((int64_t)e * S + s) * T + tt] = Lsofar;
             }
         };
         // this launch builds the transient table and, beside it, the transient state table (common.h): the state after
@@ -1353,6 +1360,29 @@ __global__ void __launch_bounds__(64 * W, OCC) logl_kernel(const KParams p)
     logl_body<NP, CPL, G, W, OCC, LAY, MODE, FLAVOR, DUMP, JUMP, BUILD>(p);
 }
 
+// The running log-likelihood of every record of the prefix table (common.h), from the sums its builder left in the record: one thread
+// per (task, frame); the sums of the dimensions are added in the order piece_value adds them (lane order: dimension 0, 1, 2).
+__global__ void prefix_L_kernel(const TrajDesc *__restrict__ trajs, int n_traj, int S, int NP, int dstar_max, int blocks_per_task,
+                                double *__restrict__ prefix, double *__restrict__ prefix_L)
+{
+    const int task = blockIdx.x / blocks_per_task; // (j * dstar_max + e) * S + s
+    const int s = task % S, e = (task / S) % dstar_max, j = task / (S * dstar_max);
+    if (j >= n_traj) return;
+    const TrajDesc &td = trajs[j];
+    const int t = (blockIdx.x % blocks_per_task) * blockDim.x + threadIdx.x;
+    if (e >= td.dstar || t >= td.T) return;
+    const int NC = NP + kDMax, REC = prefix_record_doubles(NP);
+    const int kRecP = NC * NP + kDMax, kRecE = kRecP + 1, kRecL = kRecP + 2, kRecNv = kRecP + 3;
+    const int64_t r = td.prefix_rec0 + ((int64_t)e * S + s) * td.T + t;
+    double *rec = prefix + r * REC;
+    const int nd = td.ndims[e];
+    double tot = 0.0;
+    for (int m = 0; m < nd; ++m) tot += rec[NC * NP + m];
+    const double L = piece_from_sums(tot, rec[kRecP], (int)rec[kRecE], (int)rec[kRecNv], nd);
+    rec[kRecL] = L;
+    if (prefix_L) prefix_L[r] = L;
+}
+
 __global__ void reduce_partials_kernel(const double *__restrict__ partial, double *__restrict__ out, int64_t n,
                                        int dstar_max)
 {
@@ -1616,6 +1646,17 @@ int launch_validate(const int32_t *seg_start, const int32_t *seg_state, const in
     const int bs = 256;
     hipLaunchKernelGGL(validate_kernel, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, reinterpret_cast<hipStream_t>(stream),
                        seg_start, seg_state, traj_id, order, n, K1, S, n_traj, d_err);
+    return (int)hipGetLastError();
+}
+
+int launch_prefix_L(const TrajDesc *d_trajs, int n_traj, int S, int NP, int dstar_max, int Tmax, double *d_prefix, double *d_prefix_L, void *stream)
+{
+    const int64_t tasks = (int64_t)n_traj * dstar_max * S;
+    if (tasks <= 0 || Tmax <= 0) return 0;
+    const int bpt = (Tmax + 255) / 256;
+    if (tasks * bpt >= ((int64_t)1 << 31)) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(prefix_L_kernel, dim3((unsigned)(tasks * bpt)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), d_trajs, n_traj, S, NP,
+                       dstar_max, bpt, d_prefix, d_prefix_L);
     return (int)hipGetLastError();
 }
 
