@@ -179,7 +179,7 @@ int bild_trajset_create(const bild_model *m, int n_traj, const int32_t *T,
  * flight when it is destroyed.) */
 int bild_trajset_destroy(bild_trajset *ts);
 /* Optional, before the first evaluation on the set: how many evaluations the caller expects to run on it in total.  The
- * tables of a set (see "prefix table" below) are built at its first evaluation and cost about 2 ms per trajectory of
+ * tables of a set (see "prefix table" below) are built at its first evaluation and cost about 1.5 ms per trajectory of
  * 1000 frames; they pay from a few hundred evaluations on (prefix + transient tables: >= 300) resp. a few thousand (pair
  * and state tables: >= 3000).  Without a declaration everything is built -- right for an AMIS run, wasteful for a
  * handful of single evaluations per trajectory.  Which tables exist depends on the set and on this declaration alone,
